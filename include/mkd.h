@@ -1,0 +1,152 @@
+/*
+ * mkd.h — C ABI of libmkd.so: the MI355X (gfx950) DDIM-sampling hot path of MakeupDiffuse.
+ *
+ * The reference (jiean001/MakeupDiffuse) has NO C/FFI boundary: its hot path is Python
+ * duck-typing over torch tensors.  Each entry point below names the
+ * reference interface (file:line under /root/reference) whose arithmetic it replaces; the
+ * Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - functions only ENQUEUE work on `stream` (no host sync) unless stated otherwise;
+ *   - return 0 on success, <0 on error; mkd_last_error() gives the message (thread-local);
+ *   - external layout is the reference's: NCHW fp32 latents/images, [B,77,C] fp32 context,
+ *     int64 timesteps.  Internally activations are NHWC bf16, accumulation fp32.
+ *   - no internal host threads; a context is not re-entrant (one stream at a time).
+ */
+#ifndef MKD_H
+#define MKD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mkd_ctx mkd_ctx;
+
+/* yaml control_stage_config / unet_config (diffmodels/base_diffusion_makeup.yaml:52-84). */
+typedef struct mkd_net_config {
+    int32_t in_channels;            /* 4   */
+    int32_t out_channels;           /* 4   */
+    int32_t hint_channels;          /* 6   (src_img ‖ ref_img, makeup_diffuse.py:56) */
+    int32_t model_channels;         /* 320 */
+    int32_t num_res_blocks;         /* 2   */
+    int32_t n_levels;               /* len(channel_mult) = 4 */
+    int32_t channel_mult[8];        /* 1,2,4,4 */
+    int32_t n_attention_resolutions;/* 3 */
+    int32_t attention_resolutions[8];/* 4,2,1 */
+    int32_t num_heads;              /* 8   */
+    int32_t transformer_depth;      /* 1 (only 1 is supported) */
+    int32_t context_dim;            /* 768 */
+    int32_t hint_widths[7];         /* 16,16,32,32,96,96,256 (cldm input_hint_block) */
+} mkd_net_config;
+
+#define MKD_OK              0
+#define MKD_ERR_ARG        -1
+#define MKD_ERR_HIP        -2
+#define MKD_ERR_STATE      -3
+#define MKD_ERR_UNSUPPORTED -4
+#define MKD_ERR_MISSING    -5
+
+const char* mkd_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int mkd_abi_version(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Replaces cldm.model.create_model(yaml) for the two nets (runs/test.py:27). */
+int  mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out);
+void mkd_ctx_destroy(mkd_ctx* ctx);
+
+/* Replaces model.load_state_dict (runs/test.py:59-60) for keys under
+ * "model.diffusion_model." and "control_model." (upstream names).
+ * `data` is fp32, host OR device, `shape` is host. Synchronous. Unknown names -> MKD_ERR_ARG. */
+int mkd_load_weight(mkd_ctx* ctx, const char* name, const float* data, int ndim, const int64_t* shape);
+/* Checks every expected tensor was loaded, builds fused/packed weights. Synchronous. */
+int mkd_weights_finalize(mkd_ctx* ctx);
+/* Number of parameters expected (for the 859.5 M / 361.3 M check); which: 0 unet, 1 control. */
+int64_t mkd_param_count(const mkd_ctx* ctx, int which);
+/* Enumerate the expected state_dict entries (sorted by name): count, name, shape (returns ndim <= 4). */
+int mkd_param_total(const mkd_ctx* ctx);
+const char* mkd_param_name(const mkd_ctx* ctx, int index);
+int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
+
+/* ---- conditioning ----------------------------------------------------------------------- */
+/* Binds the step-invariant conditioning for a batch (cond dict of makeup_diffuse.py:42-57,
+ * 152-166): hint = cat(c_concat,1) [B,hint_channels,8h,8w] in [0,1]; context = cat(c_crossattn,1)
+ * [B,77,context_dim]; control_scales host [13] (makeup_diffuse.py:166) or NULL for all-ones;
+ * only_mid_control (makeup_diffuse.py:162,168).  hint == NULL selects the `c_concat is None`
+ * branch (makeup_diffuse.py:160-162).  Computes and caches the ControlNet hint embedding and
+ * every cross-attention K/V projection (both independent of x and t).  (Re)allocates the
+ * workspace when batch/h/w change (the only place that allocates). */
+int mkd_prepare(mkd_ctx* ctx, int batch, int h, int w, const float* hint, const float* context,
+                const float* control_scales, int only_mid_control, void* stream);
+
+/* ---- one eps evaluation ----------------------------------------------------------------- */
+/* Replaces apply_model (makeup_diffuse.py:152-170): ControlNet -> 13 residuals x scale ->
+ * ControlledUnet.  x [B,4,h,w] fp32 NCHW, t [B] int64 (device), eps_out [B,4,h,w] fp32. */
+int mkd_eps(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream);
+
+/* ---- DDIM update ------------------------------------------------------------------------ */
+/* Replaces cddim.py:39-40 (CFG combine, eps_u may be NULL) and :56-78 (x0 / x_{t-1}).
+ * All tensors have n elements; noise may be NULL (sigma_t == 0); pred_x0 may be NULL. */
+int mkd_ddim_step(const float* x, const float* eps_c, const float* eps_u, float cfg_scale,
+                  float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,
+                  const float* noise, float temperature,
+                  float* x_prev, float* pred_x0, int64_t n, void* stream);
+
+/* ---- whole reverse loop ------------------------------------------------------------------ */
+/* Replaces MKDDIMSampler.reconstruct (cddim.py:81-100) / DDIMSampler.ddim_sampling reached from
+ * sample_log (diffusion_makeup.py:393-408) for eta == 0.  The context must have been prepared with
+ * batch B (cfg_scale == 1) or 2B with the UNCONDITIONAL conditioning first (cddim.py:25-31).
+ * Tables are host arrays of length n_steps indexed like ddim_alphas[index]; the loop runs
+ * index = n_steps-1 .. 0 with timestep = timesteps[index].  x_T, x_out: [B,4,h,w] fp32.
+ * use_graph != 0 captures one step into a hipGraph and replays it. */
+int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps,
+               const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
+               float cfg_scale, float* x_out, int use_graph, void* stream);
+
+/* ---- introspection for bench.py ----------------------------------------------------------- */
+/* Executed matmul/conv FLOPs (2 per MAC) of one mkd_eps at the prepared shape. */
+double  mkd_eps_flops(const mkd_ctx* ctx);
+/* Number of kernel launches of one mkd_eps at the prepared shape. */
+int     mkd_eps_launches(const mkd_ctx* ctx);
+/* Bytes of device memory held by the context (weights + workspace). */
+int64_t mkd_device_bytes(const mkd_ctx* ctx);
+
+/* ---- single kernels (unit parity tests; bf16 = uint16_t device buffers) -------------------- */
+/* C[M,N] = act((A[M,K] . W[N,K]^T + bias[N] + rowbias[m / rows_per_batch][n]) * scale + R[M,N]).
+ * conv3x3 != 0: A is NHWC [B,Hin,Win,Cin] (pixel stride lda), K = 9*Cin ordered (ky,kx,ci),
+ * output pixel grid Hout x Wout with `stride`, input nearest-upsampled by 2^up first; pad 1.
+ * out_f32 selects an fp32 C.  splitk 0 = auto. */
+int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                  const float* rowbias, int ldrb, int rows_per_batch,
+                  const uint16_t* R, int ldr, float scale, int act,
+                  void* C, int ldc, int out_f32, int M, int N, int K,
+                  int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
+                  int stride, int up, int splitk, void* stream);
+/* GroupNorm(32 groups, fp32 statistics) [+SiLU] over NHWC bf16 (pixel stride ld_in). */
+int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps,
+                  int silu, uint16_t* y, int ld_out, int batch, int hw, int C, int groups, void* stream);
+/* LayerNorm over the last dim of [rows, d] bf16. */
+int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
+                  uint16_t* y, int rows, int d, void* stream);
+/* softmax(q k^T * scale) v per (batch, head); q rows b*Tq+i, k/v rows b*Tk+j, head h at column h*dh. */
+int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
+                  uint16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
+                  void* stream);
+/* y[m, j] = x[m, j] * gelu_erf(x[m, inner + j]). */
+int mkd_geglu(const uint16_t* x, uint16_t* y, int rows, int inner, void* stream);
+/* direct 3x3 conv, pad 1, fp32 accumulate.  in_nchw_f32: x is fp32 NCHW else bf16 NHWC;
+ * out_nchw_f32 likewise; act 1 = SiLU; add (bf16 NHWC, may be NULL) is added after act. */
+int mkd_conv3x3_direct(const void* x, int in_nchw_f32, const uint16_t* w, const float* bias,
+                       void* y, int out_nchw_f32, int act, const uint16_t* add,
+                       int batch, int Hin, int Win, int Cin, int Cout, int stride, void* stream);
+/* fp32 [Cout,Cin,kh,kw] -> bf16 [Cout][kh][kw][Cin]. */
+int mkd_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int kh, int kw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKD_H */

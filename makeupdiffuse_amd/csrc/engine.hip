@@ -1,0 +1,977 @@
+// libmkd engine: owns the weights, the workspace and the static launch plan of one eps evaluation
+// (ControlNet -> 13 scaled residuals -> ControlledUnet; reference diffmk/makeup_diffuse.py:152-170),
+// plus the DDIM reverse loop (reference diffmk/cddim.py:81-100).  One process per GPU, one stream.
+//
+// Data layout in HBM
+//   activations : NHWC bf16, pixel stride `ld` (>= C) so channel-concats are just strided writes:
+//                 every decoder block reads one [B,H,W,C_h+C_skip] buffer whose two halves were
+//                 written in place by the previous block and by the zero-conv "combine" GEMM.
+//   weights     : bf16, conv [Cout][ky][kx][Cin], linear [N][K]; vectors (bias, norm) fp32.
+//   step-invariant caches (built in mkd_prepare): hint embedding, cross-attention K/V of every
+//                 transformer (context is constant over steps, SURVEY.md finding 5).
+#include "mkd_common.h"
+#include "../../include/mkd.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Tensor {
+    bf16_t* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0, ld = 0;
+    int rows() const { return B * H * W; }
+};
+
+struct BlockSpec {
+    int kind;  // 0 conv_in, 1 res, 2 down
+    int cin, cout;
+    bool attn, up;
+    int ds;
+};
+
+struct Param {
+    std::vector<int64_t> shape;
+    int which = 0;          // 0 unet, 1 control
+    bool loaded = false;
+    void* dev = nullptr;    // bf16 packed (ndim >= 2) or f32 (ndim == 1)
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, high = 0, cap = 0;
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base + off;
+        off += bytes;
+        if (off > high) high = off;
+        return p;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    void reset() { off = 0; high = 0; }
+};
+
+struct Epi {
+    const float* bias = nullptr;
+    const float* rowbias = nullptr; int ldrb = 0; int rpb = 1;
+    const bf16_t* R = nullptr; int ldr = 0;
+    float scale = 1.f; int act = 0;
+};
+
+typedef std::function<int(hipStream_t)> OpFn;
+
+}  // namespace
+
+struct mkd_ctx {
+    mkd_net_config cfg;
+    std::map<std::string, Param> params;
+    std::vector<std::string> res_prefixes[2];     // per net, in execution order
+    std::vector<std::string> st_prefixes[2];
+    bool finalized = false;
+
+    // fused weights (built in finalize)
+    std::map<std::string, bf16_t*> qkv_w, kv_w;   // by transformer prefix
+    bf16_t* emb_w[2] = {nullptr, nullptr};
+    float* emb_b[2] = {nullptr, nullptr};
+    int emb_total[2] = {0, 0};
+    std::map<std::string, int> emb_off;           // resblock prefix -> column offset in emb projection
+    std::vector<void*> owned;                     // every hipMalloc'd weight block
+    int64_t weight_bytes = 0;
+    bf16_t* zero_page = nullptr;
+
+    // prepared state
+    bool prepared = false;
+    int B = 0, h = 0, w = 0;
+    bool has_control = false, only_mid = false;
+    float scales[64];
+    int n_ctrl() const { return (int)encoder_spec().size() + 1; }
+    Arena persist, temp;
+    char* persist_base = nullptr; char* temp_base = nullptr;
+    size_t persist_cap = 0, temp_cap = 0;
+    float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0, splitk_need = 0;
+    float* gn_ws = nullptr; size_t gn_ws_bytes = 0, gn_need = 0;
+    std::vector<OpFn> plan_prepare, plan_eps;
+    double flops_eps = 0; int launches_eps = 0;
+    bool dry = false; bool counting_eps = false;
+    std::map<std::string, Tensor> kv_cache;       // transformer prefix -> [B*77, 2d]
+    Tensor hint_emb;
+    bf16_t* ctx_bf16 = nullptr;
+    const float* in_hint = nullptr; const float* in_context = nullptr;
+    // per-call io
+    const float* io_x = nullptr; const int64_t* io_t = nullptr; float* io_out = nullptr;
+    // sampler buffers
+    float* s_xa = nullptr; float* s_xb = nullptr; float* s_xin = nullptr; float* s_eps = nullptr;
+    int64_t* s_t = nullptr;
+
+    // ---------------------------------------------------------------------------------------------
+    int ctx_len() const { return 77; }
+    int temb_dim() const { return 4 * cfg.model_channels; }
+
+    std::vector<BlockSpec> encoder_spec() const {
+        std::vector<BlockSpec> v;
+        const int mc = cfg.model_channels;
+        v.push_back({0, cfg.in_channels, mc, false, false, 1});
+        int ch = mc, ds = 1;
+        for (int level = 0; level < cfg.n_levels; ++level) {
+            const int mult = cfg.channel_mult[level];
+            for (int i = 0; i < cfg.num_res_blocks; ++i) {
+                v.push_back({1, ch, mult * mc, attn_at(ds), false, ds});
+                ch = mult * mc;
+            }
+            if (level != cfg.n_levels - 1) {
+                ds *= 2;
+                v.push_back({2, ch, ch, false, false, ds});
+            }
+        }
+        return v;
+    }
+    std::vector<BlockSpec> decoder_spec() const {
+        std::vector<BlockSpec> enc = encoder_spec(), out;
+        std::vector<int> chans;
+        for (auto& b : enc) chans.push_back(b.cout);
+        int ch = enc.back().cout, ds = enc.back().ds;
+        const int mc = cfg.model_channels;
+        for (int level = cfg.n_levels - 1; level >= 0; --level) {
+            const int mult = cfg.channel_mult[level];
+            for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+                const int ich = chans.back(); chans.pop_back();
+                const bool up = level > 0 && i == cfg.num_res_blocks;
+                out.push_back({1, ch + ich, mc * mult, attn_at(ds), up, ds});
+                ch = mc * mult;
+                if (up) ds /= 2;
+            }
+        }
+        return out;
+    }
+    bool attn_at(int ds) const {
+        for (int i = 0; i < cfg.n_attention_resolutions; ++i)
+            if (cfg.attention_resolutions[i] == ds) return true;
+        return false;
+    }
+
+    void add_param(const std::string& name, std::vector<int64_t> shape, int which) {
+        Param p; p.shape = std::move(shape); p.which = which;
+        params[name] = p;
+    }
+    void add_res(const std::string& p, int cin, int cout, int which) {
+        const int te = temb_dim();
+        add_param(p + ".in_layers.0.weight", {cin}, which); add_param(p + ".in_layers.0.bias", {cin}, which);
+        add_param(p + ".in_layers.2.weight", {cout, cin, 3, 3}, which); add_param(p + ".in_layers.2.bias", {cout}, which);
+        add_param(p + ".emb_layers.1.weight", {cout, te}, which); add_param(p + ".emb_layers.1.bias", {cout}, which);
+        add_param(p + ".out_layers.0.weight", {cout}, which); add_param(p + ".out_layers.0.bias", {cout}, which);
+        add_param(p + ".out_layers.3.weight", {cout, cout, 3, 3}, which); add_param(p + ".out_layers.3.bias", {cout}, which);
+        if (cin != cout) {
+            add_param(p + ".skip_connection.weight", {cout, cin, 1, 1}, which);
+            add_param(p + ".skip_connection.bias", {cout}, which);
+        }
+        res_prefixes[which].push_back(p);
+    }
+    void add_st(const std::string& p, int ch, int which) {
+        const int cd = cfg.context_dim;
+        add_param(p + ".norm.weight", {ch}, which); add_param(p + ".norm.bias", {ch}, which);
+        add_param(p + ".proj_in.weight", {ch, ch, 1, 1}, which); add_param(p + ".proj_in.bias", {ch}, which);
+        add_param(p + ".proj_out.weight", {ch, ch, 1, 1}, which); add_param(p + ".proj_out.bias", {ch}, which);
+        const std::string t = p + ".transformer_blocks.0";
+        for (int a = 1; a <= 2; ++a) {
+            const std::string ap = t + ".attn" + std::to_string(a);
+            const int kd = a == 1 ? ch : cd;
+            add_param(ap + ".to_q.weight", {ch, ch}, which);
+            add_param(ap + ".to_k.weight", {ch, kd}, which);
+            add_param(ap + ".to_v.weight", {ch, kd}, which);
+            add_param(ap + ".to_out.0.weight", {ch, ch}, which);
+            add_param(ap + ".to_out.0.bias", {ch}, which);
+        }
+        for (int n = 1; n <= 3; ++n) {
+            add_param(t + ".norm" + std::to_string(n) + ".weight", {ch}, which);
+            add_param(t + ".norm" + std::to_string(n) + ".bias", {ch}, which);
+        }
+        add_param(t + ".ff.net.0.proj.weight", {8 * ch, ch}, which); add_param(t + ".ff.net.0.proj.bias", {8 * ch}, which);
+        add_param(t + ".ff.net.2.weight", {ch, 4 * ch}, which); add_param(t + ".ff.net.2.bias", {ch}, which);
+        st_prefixes[which].push_back(p);
+    }
+    static std::string net_prefix(int which) { return which == 0 ? "model.diffusion_model." : "control_model."; }
+
+    void build_param_spec() {
+        const int mc = cfg.model_channels, te = temb_dim();
+        for (int which = 0; which < 2; ++which) {
+            const std::string P = net_prefix(which);
+            add_param(P + "time_embed.0.weight", {te, mc}, which); add_param(P + "time_embed.0.bias", {te}, which);
+            add_param(P + "time_embed.2.weight", {te, te}, which); add_param(P + "time_embed.2.bias", {te}, which);
+            auto enc = encoder_spec();
+            for (size_t i = 0; i < enc.size(); ++i) {
+                const std::string p = P + "input_blocks." + std::to_string(i);
+                const BlockSpec& b = enc[i];
+                if (b.kind == 0) {
+                    add_param(p + ".0.weight", {b.cout, b.cin, 3, 3}, which); add_param(p + ".0.bias", {b.cout}, which);
+                } else if (b.kind == 1) {
+                    add_res(p + ".0", b.cin, b.cout, which);
+                    if (b.attn) add_st(p + ".1", b.cout, which);
+                } else {
+                    add_param(p + ".0.op.weight", {b.cout, b.cin, 3, 3}, which); add_param(p + ".0.op.bias", {b.cout}, which);
+                }
+            }
+            const int ch = enc.back().cout;
+            add_res(P + "middle_block.0", ch, ch, which);
+            add_st(P + "middle_block.1", ch, which);
+            add_res(P + "middle_block.2", ch, ch, which);
+            if (which == 0) {
+                auto dec = decoder_spec();
+                for (size_t i = 0; i < dec.size(); ++i) {
+                    const std::string p = P + "output_blocks." + std::to_string(i);
+                    const BlockSpec& b = dec[i];
+                    add_res(p + ".0", b.cin, b.cout, which);
+                    int k = 1;
+                    if (b.attn) { add_st(p + ".1", b.cout, which); k = 2; }
+                    if (b.up) {
+                        add_param(p + "." + std::to_string(k) + ".conv.weight", {b.cout, b.cout, 3, 3}, which);
+                        add_param(p + "." + std::to_string(k) + ".conv.bias", {b.cout}, which);
+                    }
+                }
+                add_param(P + "out.0.weight", {mc}, which); add_param(P + "out.0.bias", {mc}, which);
+                add_param(P + "out.2.weight", {cfg.out_channels, mc, 3, 3}, which); add_param(P + "out.2.bias", {cfg.out_channels}, which);
+            } else {
+                int widths[9];
+                widths[0] = cfg.hint_channels;
+                for (int j = 0; j < 7; ++j) widths[j + 1] = cfg.hint_widths[j];
+                widths[8] = mc;
+                for (int j = 0; j < 8; ++j) {
+                    add_param(P + "input_hint_block." + std::to_string(2 * j) + ".weight", {widths[j + 1], widths[j], 3, 3}, which);
+                    add_param(P + "input_hint_block." + std::to_string(2 * j) + ".bias", {widths[j + 1]}, which);
+                }
+                for (size_t i = 0; i < enc.size(); ++i) {
+                    add_param(P + "zero_convs." + std::to_string(i) + ".0.weight", {enc[i].cout, enc[i].cout, 1, 1}, which);
+                    add_param(P + "zero_convs." + std::to_string(i) + ".0.bias", {enc[i].cout}, which);
+                }
+                add_param(P + "middle_block_out.0.weight", {ch, ch, 1, 1}, which);
+                add_param(P + "middle_block_out.0.bias", {ch}, which);
+            }
+        }
+    }
+
+    // ---- weights ----------------------------------------------------------------------------------
+    int dev_alloc(void** out, size_t bytes) {
+        MKD_HIP_CHECK(hipMalloc(out, bytes ? bytes : 16));
+        owned.push_back(*out);
+        weight_bytes += (int64_t)bytes;
+        return 0;
+    }
+    const bf16_t* wb(const std::string& name) const {
+        auto it = params.find(name);
+        return it == params.end() ? nullptr : (const bf16_t*)it->second.dev;
+    }
+    const float* wf(const std::string& name) const {
+        auto it = params.find(name);
+        return it == params.end() ? nullptr : (const float*)it->second.dev;
+    }
+
+    int load_weight(const char* name, const float* data, int ndim, const int64_t* shape) {
+        auto it = params.find(name);
+        if (it == params.end()) return mkd_fail(MKD_ERR_ARG, std::string("unknown weight name: ") + name);
+        Param& p = it->second;
+        if ((int)p.shape.size() != ndim) return mkd_fail(MKD_ERR_ARG, std::string("rank mismatch for ") + name);
+        for (int i = 0; i < ndim; ++i)
+            if (p.shape[i] != shape[i]) return mkd_fail(MKD_ERR_ARG, std::string("shape mismatch for ") + name);
+        const int64_t n = p.numel();
+        float* stage = nullptr;
+        MKD_HIP_CHECK(hipMalloc((void**)&stage, n * sizeof(float)));
+        hipError_t e = hipMemcpy(stage, data, n * sizeof(float), hipMemcpyDefault);
+        if (e != hipSuccess) { hipFree(stage); return mkd_fail(MKD_ERR_HIP, std::string("hipMemcpy weight: ") + hipGetErrorString(e)); }
+        int rc = 0;
+        if (ndim == 1) {
+            if (!p.dev) rc = dev_alloc(&p.dev, n * sizeof(float));
+            if (!rc) {
+                e = hipMemcpy(p.dev, stage, n * sizeof(float), hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, hipGetErrorString(e));
+            }
+        } else {
+            if (!p.dev) rc = dev_alloc(&p.dev, n * sizeof(bf16_t));
+            if (!rc) {
+                if (ndim == 4) rc = launch_pack_conv_weight(stage, (bf16_t*)p.dev, (int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], 0);
+                else rc = launch_f32_to_bf16(stage, (bf16_t*)p.dev, n, 0);
+            }
+        }
+        e = hipDeviceSynchronize();
+        hipFree(stage);
+        if (rc) return rc;
+        if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("load_weight sync: ") + hipGetErrorString(e));
+        p.loaded = true;
+        finalized = false;
+        return 0;
+    }
+
+    int concat_rows(bf16_t** out, const std::vector<std::string>& names) {
+        size_t total = 0;
+        for (auto& n : names) total += (size_t)params.at(n).numel();
+        void* d = nullptr;
+        int rc = dev_alloc(&d, total * sizeof(bf16_t));
+        if (rc) return rc;
+        size_t off = 0;
+        for (auto& n : names) {
+            const Param& p = params.at(n);
+            MKD_HIP_CHECK(hipMemcpy((bf16_t*)d + off, p.dev, p.numel() * sizeof(bf16_t), hipMemcpyDeviceToDevice));
+            off += p.numel();
+        }
+        *out = (bf16_t*)d;
+        return 0;
+    }
+
+    int finalize() {
+        for (auto& kv : params)
+            if (!kv.second.loaded) return mkd_fail(MKD_ERR_MISSING, "weight not loaded: " + kv.first);
+        if (finalized) return 0;
+        if (!zero_page) {
+            void* z = nullptr;
+            int rc = dev_alloc(&z, 4096);
+            if (rc) return rc;
+            MKD_HIP_CHECK(hipMemset(z, 0, 4096));
+            zero_page = (bf16_t*)z;
+        }
+        qkv_w.clear(); kv_w.clear(); emb_off.clear();
+        for (int which = 0; which < 2; ++which) {
+            for (auto& p : st_prefixes[which]) {
+                const std::string t = p + ".transformer_blocks.0";
+                bf16_t* q = nullptr; bf16_t* k = nullptr;
+                int rc = concat_rows(&q, {t + ".attn1.to_q.weight", t + ".attn1.to_k.weight", t + ".attn1.to_v.weight"});
+                if (rc) return rc;
+                rc = concat_rows(&k, {t + ".attn2.to_k.weight", t + ".attn2.to_v.weight"});
+                if (rc) return rc;
+                qkv_w[p] = q; kv_w[p] = k;
+            }
+            std::vector<std::string> wn;
+            int off = 0;
+            for (auto& p : res_prefixes[which]) {
+                wn.push_back(p + ".emb_layers.1.weight");
+                emb_off[p] = off;
+                off += (int)params.at(p + ".emb_layers.1.bias").numel();
+            }
+            emb_total[which] = off;
+            int rc = concat_rows(&emb_w[which], wn);
+            if (rc) return rc;
+            void* b = nullptr;
+            rc = dev_alloc(&b, off * sizeof(float));
+            if (rc) return rc;
+            emb_b[which] = (float*)b;
+            for (auto& p : res_prefixes[which]) {
+                const Param& bp = params.at(p + ".emb_layers.1.bias");
+                MKD_HIP_CHECK(hipMemcpy(emb_b[which] + emb_off[p], bp.dev, bp.numel() * sizeof(float), hipMemcpyDeviceToDevice));
+            }
+        }
+        MKD_HIP_CHECK(hipDeviceSynchronize());
+        finalized = true;
+        prepared = false;
+        return 0;
+    }
+
+    // ---- plan building ------------------------------------------------------------------------------
+    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops) {
+        if (counting_eps) { launches_eps += launches; flops_eps += flops; }
+        if (!dry) plan.push_back(std::move(f));
+    }
+    std::vector<OpFn>* cur_plan = nullptr;
+
+    Tensor talloc(Arena& a, int B_, int H_, int W_, int C_) {
+        Tensor t; t.B = B_; t.H = H_; t.W = W_; t.C = C_; t.ld = C_;
+        t.p = (bf16_t*)a.alloc((size_t)B_ * H_ * W_ * C_ * sizeof(bf16_t));
+        return t;
+    }
+
+    void op_gemm(GemmArgs a) {
+        a.zero = zero_page;
+        a.splitk = 0;
+        const int s = gemm_pick_splitk(a.M, a.N, a.K);
+        const size_t need = gemm_ws_bytes(a.M, a.N, s);
+        if (need > splitk_need) splitk_need = need;
+        mkd_ctx* self = this;
+        push(*cur_plan, [self, a](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws; return launch_gemm(b, st); },
+             s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K);
+    }
+    void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
+        GemmArgs a; memset(&a, 0, sizeof(a));
+        a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = e.bias; a.rowbias = e.rowbias; a.ldrb = e.ldrb;
+        a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
+        a.C = C; a.ldc = ldc; a.out_f32 = f32out ? 1 : 0; a.M = M; a.N = N; a.K = K; a.conv = 0;
+        op_gemm(a);
+    }
+    // 3x3 conv, pad 1; returns output spatial dims through Hout/Wout
+    void op_conv(const Tensor& in, const bf16_t* W, int N, int stride, int up, const Epi& e, bf16_t* C, int ldc) {
+        GemmArgs a; memset(&a, 0, sizeof(a));
+        const int Hs = in.H << up, Ws = in.W << up;
+        const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
+        a.A = in.p; a.lda = in.ld; a.W = W; a.ldw = 9 * in.C; a.bias = e.bias; a.rowbias = e.rowbias; a.ldrb = e.ldrb;
+        a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
+        a.C = C; a.ldc = ldc; a.out_f32 = 0; a.M = in.B * Ho * Wo; a.N = N; a.K = 9 * in.C; a.conv = 1;
+        a.Hin = in.H; a.Win = in.W; a.Cin = in.C; a.Hout = Ho; a.Wout = Wo; a.stride = stride; a.up = up;
+        op_gemm(a);
+    }
+    void op_gn(const Tensor& in, const float* gamma, const float* beta, float eps, int silu, bf16_t* out, int ld_out) {
+        const size_t need = groupnorm_partials_bytes(in.B, in.H * in.W, 32);
+        if (need > gn_need) gn_need = need;
+        mkd_ctx* self = this;
+        Tensor t = in;
+        push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out](hipStream_t st) {
+            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws, st);
+        }, 2, 0.0);
+    }
+    void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
+        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0);
+    }
+    void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
+                 int B_, int Tq, int Tk, int heads, int dh) {
+        const float scale = 1.0f / sqrtf((float)dh);
+        push(*cur_plan, [=](hipStream_t st) { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B_, Tq, Tk, heads, dh, scale, st); },
+             1, 4.0 * B_ * heads * (double)Tq * Tk * dh);
+    }
+    void op_geglu(const bf16_t* x, bf16_t* y, int rows, int inner) {
+        push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0);
+    }
+    void op_copy(const bf16_t* src, int ld_src, bf16_t* dst, int ld_dst, int rows, int cols) {
+        push(*cur_plan, [=](hipStream_t st) { return launch_copy_strided(src, ld_src, dst, ld_dst, rows, cols, st); }, 1, 0.0);
+    }
+
+    // ResBlock (App. A.2).  x may be a concat buffer (ld == C).  Writes [rows, cout] at (out, ldo).
+    void resblock(const std::string& p, const Tensor& x, int cout, const float* embproj, int ld_emb, bf16_t* out, int ldo) {
+        const size_t mk = temp.mark();
+        const int rows = x.rows(), hw = x.H * x.W;
+        Tensor t1 = talloc(temp, x.B, x.H, x.W, x.C);
+        op_gn(x, wf(p + ".in_layers.0.weight"), wf(p + ".in_layers.0.bias"), 1e-5f, 1, t1.p, t1.ld);
+        Tensor t2 = talloc(temp, x.B, x.H, x.W, cout);
+        Epi e1; e1.bias = wf(p + ".in_layers.2.bias"); e1.rowbias = embproj + emb_off.at(p); e1.ldrb = ld_emb; e1.rpb = hw;
+        op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
+        Tensor t3 = talloc(temp, x.B, x.H, x.W, cout);
+        op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
+        Epi e2; e2.bias = wf(p + ".out_layers.3.bias");
+        if (x.C != cout) {
+            Tensor t4 = talloc(temp, x.B, x.H, x.W, cout);
+            Epi es; es.bias = wf(p + ".skip_connection.bias");
+            op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
+            e2.R = t4.p; e2.ldr = t4.ld;
+        } else {
+            e2.R = x.p; e2.ldr = x.ld;
+        }
+        op_conv(t3, wb(p + ".out_layers.3.weight"), cout, 1, 0, e2, out, ldo);
+        temp.release(mk);
+    }
+
+    // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
+    void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo) {
+        const size_t mk = temp.mark();
+        const int d = x.C, M = x.rows(), T = x.H * x.W, heads = cfg.num_heads, dh = d / heads;
+        const std::string t = p + ".transformer_blocks.0";
+        auto buf = [&](int cols) { return (bf16_t*)temp.alloc((size_t)M * cols * sizeof(bf16_t)); };
+        bf16_t* g = buf(d);
+        op_gn(x, wf(p + ".norm.weight"), wf(p + ".norm.bias"), 1e-6f, 0, g, d);
+        bf16_t* h0 = buf(d);
+        { Epi e; e.bias = wf(p + ".proj_in.bias"); op_linear(g, d, M, d, wb(p + ".proj_in.weight"), d, e, h0, d); }
+        // self attention
+        bf16_t* n1 = buf(d);
+        op_ln(h0, wf(t + ".norm1.weight"), wf(t + ".norm1.bias"), n1, M, d);
+        bf16_t* qkv = buf(3 * d);
+        { Epi e; op_linear(n1, d, M, d, qkv_w.at(p), 3 * d, e, qkv, 3 * d); }
+        bf16_t* a1 = buf(d);
+        op_attn(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, a1, d, x.B, T, T, heads, dh);
+        bf16_t* h1 = buf(d);
+        { Epi e; e.bias = wf(t + ".attn1.to_out.0.bias"); e.R = h0; e.ldr = d;
+          op_linear(a1, d, M, d, wb(t + ".attn1.to_out.0.weight"), d, e, h1, d); }
+        // cross attention (K/V cached at prepare)
+        bf16_t* n2 = buf(d);
+        op_ln(h1, wf(t + ".norm2.weight"), wf(t + ".norm2.bias"), n2, M, d);
+        bf16_t* q2 = buf(d);
+        { Epi e; op_linear(n2, d, M, d, wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
+        const Tensor& kv = kv_cache.at(p);
+        bf16_t* a2 = buf(d);
+        op_attn(q2, d, kv.p, 2 * d, kv.p + d, 2 * d, a2, d, x.B, T, ctx_len(), heads, dh);
+        bf16_t* h2 = buf(d);
+        { Epi e; e.bias = wf(t + ".attn2.to_out.0.bias"); e.R = h1; e.ldr = d;
+          op_linear(a2, d, M, d, wb(t + ".attn2.to_out.0.weight"), d, e, h2, d); }
+        // GEGLU feed-forward
+        bf16_t* n3 = buf(d);
+        op_ln(h2, wf(t + ".norm3.weight"), wf(t + ".norm3.bias"), n3, M, d);
+        bf16_t* ff1 = buf(8 * d);
+        { Epi e; e.bias = wf(t + ".ff.net.0.proj.bias"); op_linear(n3, d, M, d, wb(t + ".ff.net.0.proj.weight"), 8 * d, e, ff1, 8 * d); }
+        bf16_t* gg = buf(4 * d);
+        op_geglu(ff1, gg, M, 4 * d);
+        bf16_t* h3 = buf(d);
+        { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
+          op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
+        { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld;
+          op_linear(h3, d, M, d, wb(p + ".proj_out.weight"), d, e, out, ldo); }
+        temp.release(mk);
+    }
+
+    // time embedding MLP + every ResBlock's emb projection in one GEMM -> fp32 [B, emb_total]
+    float* time_embedding(int which) {
+        const std::string P = net_prefix(which);
+        const int mc = cfg.model_channels, te = temb_dim();
+        bf16_t* s0 = (bf16_t*)persist.alloc((size_t)B * mc * sizeof(bf16_t));
+        mkd_ctx* self = this;
+        const int Bn = B;
+        push(*cur_plan, [self, s0, Bn, mc](hipStream_t st) { return launch_timestep_embedding(self->io_t, s0, Bn, mc, st); }, 1, 0.0);
+        bf16_t* s1 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
+        { Epi e; e.bias = wf(P + "time_embed.0.bias"); e.act = 1; op_linear(s0, mc, B, mc, wb(P + "time_embed.0.weight"), te, e, s1, te); }
+        bf16_t* s2 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
+        // every consumer applies SiLU to emb first (emb_layers = [SiLU, Linear]) -> fold it here
+        { Epi e; e.bias = wf(P + "time_embed.2.bias"); e.act = 1; op_linear(s1, te, B, te, wb(P + "time_embed.2.weight"), te, e, s2, te); }
+        float* proj = (float*)persist.alloc((size_t)B * emb_total[which] * sizeof(float));
+        { Epi e; e.bias = emb_b[which]; op_linear(s2, te, B, te, emb_w[which], emb_total[which], e, proj, emb_total[which], true); }
+        return proj;
+    }
+
+    // encoder + middle block of one net. feats[i] = output of input_blocks[i]; returns middle output.
+    Tensor encoder(int which, const float* embproj, std::vector<Tensor>& feats) {
+        const std::string P = net_prefix(which);
+        auto enc = encoder_spec();
+        const int ld_emb = emb_total[which];
+        mkd_ctx* self = this;
+        Tensor hcur;
+        for (size_t i = 0; i < enc.size(); ++i) {
+            const BlockSpec& b = enc[i];
+            const std::string p = P + "input_blocks." + std::to_string(i);
+            if (b.kind == 0) {
+                Tensor o = talloc(persist, B, h, w, b.cout);
+                const bf16_t* wgt = wb(p + ".0.weight"); const float* bias = wf(p + ".0.bias");
+                const bf16_t* add = which == 1 ? hint_emb.p : nullptr;
+                const int Bn = B, hh = h, ww = w, cin = b.cin, cout = b.cout;
+                push(*cur_plan, [self, wgt, bias, o, add, Bn, hh, ww, cin, cout](hipStream_t st) {
+                    return launch_conv3x3_direct(self->io_x, 1, wgt, bias, o.p, 0, 0, add, Bn, hh, ww, cin, cout, 1, st);
+                }, 1, 2.0 * B * h * w * b.cout * 9 * b.cin);
+                hcur = o;
+            } else if (b.kind == 1) {
+                Tensor o = talloc(persist, hcur.B, hcur.H, hcur.W, b.cout);
+                if (b.attn) {
+                    const size_t mk = temp.mark();
+                    Tensor r = talloc(temp, hcur.B, hcur.H, hcur.W, b.cout);
+                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, r.p, r.ld);
+                    spatial_transformer(p + ".1", r, o.p, o.ld);
+                    temp.release(mk);
+                } else {
+                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, o.p, o.ld);
+                }
+                hcur = o;
+            } else {
+                Tensor o = talloc(persist, hcur.B, (hcur.H - 1) / 2 + 1, (hcur.W - 1) / 2 + 1, b.cout);
+                Epi e; e.bias = wf(p + ".0.op.bias");
+                op_conv(hcur, wb(p + ".0.op.weight"), b.cout, 2, 0, e, o.p, o.ld);
+                hcur = o;
+            }
+            feats.push_back(hcur);
+        }
+        const int ch = hcur.C;
+        const size_t mk = temp.mark();
+        Tensor m1 = talloc(temp, hcur.B, hcur.H, hcur.W, ch);
+        resblock(P + "middle_block.0", hcur, ch, embproj, ld_emb, m1.p, m1.ld);
+        Tensor m2 = talloc(temp, hcur.B, hcur.H, hcur.W, ch);
+        spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld);
+        Tensor m3 = talloc(persist, hcur.B, hcur.H, hcur.W, ch);
+        resblock(P + "middle_block.2", m2, ch, embproj, ld_emb, m3.p, m3.ld);
+        temp.release(mk);
+        return m3;
+    }
+
+    void build_prepare_plan() {
+        cur_plan = &plan_prepare;
+        counting_eps = false;
+        mkd_ctx* self = this;
+        const int L = ctx_len(), cd = cfg.context_dim;
+        ctx_bf16 = (bf16_t*)persist.alloc((size_t)B * L * cd * sizeof(bf16_t));
+        {
+            bf16_t* dst = ctx_bf16; const int64_t n = (int64_t)B * L * cd;
+            push(*cur_plan, [self, dst, n](hipStream_t st) { return launch_f32_to_bf16(self->in_context, dst, n, st); }, 1, 0.0);
+        }
+        kv_cache.clear();
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && !has_control) continue;
+            for (auto& p : st_prefixes[which]) {
+                const int d = (int)params.at(p + ".norm.weight").numel();
+                Tensor kv; kv.B = B; kv.H = 1; kv.W = L; kv.C = 2 * d; kv.ld = 2 * d;
+                kv.p = (bf16_t*)persist.alloc((size_t)B * L * 2 * d * sizeof(bf16_t));
+                Epi e;
+                op_linear(ctx_bf16, cd, B * L, cd, kv_w.at(p), 2 * d, e, kv.p, 2 * d);
+                kv_cache[p] = kv;
+            }
+        }
+        if (has_control) {
+            const std::string P = net_prefix(1);
+            const int strides[8] = {1, 1, 2, 1, 2, 1, 2, 1};
+            int widths[9];
+            widths[0] = cfg.hint_channels;
+            for (int j = 0; j < 7; ++j) widths[j + 1] = cfg.hint_widths[j];
+            widths[8] = cfg.model_channels;
+            const int H0 = 8 * h, W0 = 8 * w;
+            const size_t mk = temp.mark();
+            Tensor cur = talloc(temp, B, H0, W0, widths[1]);
+            {
+                const bf16_t* wgt = wb(P + "input_hint_block.0.weight"); const float* bias = wf(P + "input_hint_block.0.bias");
+                const int Bn = B, cin = widths[0], cout = widths[1];
+                push(*cur_plan, [self, wgt, bias, cur, Bn, H0, W0, cin, cout](hipStream_t st) {
+                    return launch_conv3x3_direct(self->in_hint, 1, wgt, bias, cur.p, 0, 1, nullptr, Bn, H0, W0, cin, cout, 1, st);
+                }, 1, 0.0);
+            }
+            for (int j = 1; j < 8; ++j) {
+                const int s = strides[j];
+                const int Ho = (cur.H - 1) / s + 1, Wo = (cur.W - 1) / s + 1;
+                Tensor nxt = (j == 7) ? talloc(persist, B, Ho, Wo, widths[j + 1]) : talloc(temp, B, Ho, Wo, widths[j + 1]);
+                Epi e; e.bias = wf(P + "input_hint_block." + std::to_string(2 * j) + ".bias"); e.act = (j == 7) ? 0 : 1;
+                op_conv(cur, wb(P + "input_hint_block." + std::to_string(2 * j) + ".weight"), widths[j + 1], s, 0, e, nxt.p, nxt.ld);
+                cur = nxt;
+            }
+            hint_emb = cur;
+            temp.release(mk);
+        }
+    }
+
+    void build_eps_plan() {
+        cur_plan = &plan_eps;
+        counting_eps = true;
+        flops_eps = 0; launches_eps = 0;
+        mkd_ctx* self = this;
+        std::vector<Tensor> cn_feats, hs;
+        Tensor cn_mid, u_mid;
+        if (has_control) {
+            float* ep = time_embedding(1);
+            cn_mid = encoder(1, ep, cn_feats);
+        }
+        float* ep0 = time_embedding(0);
+        u_mid = encoder(0, ep0, hs);
+
+        auto dec = decoder_spec();
+        const std::string P = net_prefix(0), PC = net_prefix(1);
+        // first concat buffer: [mid (+control mid) | hs[last] (+control)]
+        Tensor cat;
+        int n_skip = (int)hs.size();
+        for (size_t i = 0; i < dec.size(); ++i) {
+            const BlockSpec& b = dec[i];
+            const Tensor& skip = hs[n_skip - 1 - (int)i];
+            const int ch_h = b.cin - skip.C;
+            if (i == 0) {
+                cat = talloc(persist, skip.B, skip.H, skip.W, b.cin);
+                if (has_control) {
+                    Epi e; e.bias = wf(PC + "middle_block_out.0.bias"); e.scale = scales[n_ctrl() - 1]; e.R = u_mid.p; e.ldr = u_mid.ld;
+                    op_linear(cn_mid.p, cn_mid.ld, cn_mid.rows(), cn_mid.C, wb(PC + "middle_block_out.0.weight"), cn_mid.C, e, cat.p, cat.ld);
+                } else {
+                    op_copy(u_mid.p, u_mid.ld, cat.p, cat.ld, u_mid.rows(), u_mid.C);
+                }
+            }
+            // skip half of this block's concat input
+            const int si = n_skip - 1 - (int)i;
+            if (has_control && !only_mid) {
+                const Tensor& cf = cn_feats[si];
+                Epi e; e.bias = wf(PC + "zero_convs." + std::to_string(si) + ".0.bias"); e.scale = scales[si]; e.R = skip.p; e.ldr = skip.ld;
+                op_linear(cf.p, cf.ld, cf.rows(), cf.C, wb(PC + "zero_convs." + std::to_string(si) + ".0.weight"), cf.C, e, cat.p + ch_h, cat.ld);
+            } else {
+                op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
+            }
+            // where does this block's output go?  next concat buffer's h half (or the final tensor)
+            const std::string p = P + "output_blocks." + std::to_string(i);
+            Tensor nxt_cat; bf16_t* dst; int dst_ld;
+            const int outH = b.up ? cat.H * 2 : cat.H, outW = b.up ? cat.W * 2 : cat.W;
+            if (i + 1 < dec.size()) {
+                nxt_cat = talloc(persist, cat.B, outH, outW, dec[i + 1].cin);
+                dst = nxt_cat.p; dst_ld = nxt_cat.ld;
+            } else {
+                nxt_cat = talloc(persist, cat.B, outH, outW, b.cout);
+                dst = nxt_cat.p; dst_ld = nxt_cat.ld;
+            }
+            const size_t mk = temp.mark();
+            const int stages = 1 + (b.attn ? 1 : 0) + (b.up ? 1 : 0);
+            Tensor cur_in = cat;
+            int stage = 0;
+            // ResBlock
+            {
+                ++stage;
+                Tensor o; bf16_t* op_; int ol;
+                if (stage == stages) { op_ = dst; ol = dst_ld; o.p = dst; }
+                else { o = talloc(temp, cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
+                resblock(p + ".0", cur_in, b.cout, ep0, emb_total[0], op_, ol);
+                cur_in.p = op_; cur_in.C = b.cout; cur_in.ld = ol;
+            }
+            if (b.attn) {
+                ++stage;
+                bf16_t* op_; int ol;
+                if (stage == stages) { op_ = dst; ol = dst_ld; }
+                else { Tensor o = talloc(temp, cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
+                spatial_transformer(p + ".1", cur_in, op_, ol);
+                cur_in.p = op_; cur_in.ld = ol;
+            }
+            if (b.up) {
+                const int k = b.attn ? 2 : 1;
+                Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias");
+                op_conv(cur_in, wb(p + "." + std::to_string(k) + ".conv.weight"), b.cout, 1, 1, e, dst, dst_ld);
+            }
+            temp.release(mk);
+            cat = nxt_cat;
+        }
+        // out: GN32 + SiLU + conv3x3 C -> out_channels (fp32 NCHW)
+        {
+            const size_t mk = temp.mark();
+            Tensor g = talloc(temp, cat.B, cat.H, cat.W, cat.C);
+            op_gn(cat, wf(P + "out.0.weight"), wf(P + "out.0.bias"), 1e-5f, 1, g.p, g.ld);
+            const bf16_t* wgt = wb(P + "out.2.weight"); const float* bias = wf(P + "out.2.bias");
+            const int Bn = B, hh = h, ww = w, cin = cat.C, cout = cfg.out_channels;
+            push(*cur_plan, [self, g, wgt, bias, Bn, hh, ww, cin, cout](hipStream_t st) {
+                return launch_conv3x3_direct(g.p, 0, wgt, bias, self->io_out, 1, 0, nullptr, Bn, hh, ww, cin, cout, 1, st);
+            }, 1, 2.0 * B * h * w * cfg.out_channels * 9 * cat.C);
+            temp.release(mk);
+        }
+        counting_eps = false;
+    }
+
+    int ensure(void** p, size_t* have, size_t need) {
+        if (*have >= need && *p) return 0;
+        if (*p) { hipFree(*p); *p = nullptr; *have = 0; }
+        MKD_HIP_CHECK(hipMalloc(p, need ? need : 256));
+        *have = need;
+        return 0;
+    }
+
+    int prepare(int batch, int hh, int ww, const float* hint, const float* context, const float* control_scales,
+                int only_mid_control, hipStream_t stream) {
+        if (!finalized) return mkd_fail(MKD_ERR_STATE, "mkd_prepare before mkd_weights_finalize");
+        if (batch <= 0 || hh <= 0 || ww <= 0 || !context) return mkd_fail(MKD_ERR_ARG, "mkd_prepare: bad arguments");
+        const int down = 1 << (cfg.n_levels - 1);
+        if (hh % down || ww % down) return mkd_fail(MKD_ERR_ARG, "mkd_prepare: latent h, w must be multiples of " + std::to_string(down));
+        const bool ctrl = hint != nullptr;
+        const bool same = prepared && batch == B && hh == h && ww == w && ctrl == has_control && (only_mid_control != 0) == only_mid;
+        bool same_scales = same;
+        for (int i = 0; i < n_ctrl() && same_scales; ++i) same_scales = scales[i] == (control_scales ? control_scales[i] : 1.f);
+        in_hint = hint; in_context = context;
+        if (!same_scales) {
+            B = batch; h = hh; w = ww; has_control = ctrl; only_mid = only_mid_control != 0;
+            for (int i = 0; i < n_ctrl(); ++i) scales[i] = control_scales ? control_scales[i] : 1.f;
+            prepared = false;
+            // pass 1: dry run to size the arenas (pointers are offsets from null and never dereferenced)
+            dry = true;
+            persist.base = nullptr; temp.base = nullptr; persist.reset(); temp.reset();
+            splitk_need = 0; gn_need = 0;
+            plan_prepare.clear(); plan_eps.clear();
+            build_prepare_plan(); build_eps_plan();
+            const size_t pneed = persist.high + 256, tneed = temp.high + 256;
+            int rc = ensure((void**)&persist_base, &persist_cap, pneed); if (rc) return rc;
+            rc = ensure((void**)&temp_base, &temp_cap, tneed); if (rc) return rc;
+            rc = ensure((void**)&splitk_ws, &splitk_ws_bytes, splitk_need); if (rc) return rc;
+            rc = ensure((void**)&gn_ws, &gn_ws_bytes, gn_need); if (rc) return rc;
+            // pass 2: real plan
+            dry = false;
+            persist.base = persist_base; temp.base = temp_base; persist.reset(); temp.reset();
+            build_prepare_plan(); build_eps_plan();
+            // sampler buffers
+            const size_t lat = (size_t)B * cfg.in_channels * h * w * sizeof(float);
+            for (float** q : {&s_xa, &s_xb, &s_xin, &s_eps}) {
+                if (*q) { hipFree(*q); *q = nullptr; }
+                MKD_HIP_CHECK(hipMalloc((void**)q, lat));
+            }
+            if (s_t) { hipFree(s_t); s_t = nullptr; }
+            MKD_HIP_CHECK(hipMalloc((void**)&s_t, (size_t)B * sizeof(int64_t)));
+        }
+        for (auto& f : plan_prepare) { int rc = f(stream); if (rc) return rc; }
+        prepared = true;
+        return 0;
+    }
+
+    int eps(const float* x, const int64_t* t, float* out, hipStream_t stream) {
+        if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps before mkd_prepare");
+        if (!x || !t || !out) return mkd_fail(MKD_ERR_ARG, "mkd_eps: null pointer");
+        io_x = x; io_t = t; io_out = out;
+        for (auto& f : plan_eps) { int rc = f(stream); if (rc) return rc; }
+        return 0;
+    }
+
+    int sample(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
+               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
+        (void)use_graph;
+        if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_sample before mkd_prepare");
+        const bool cfg_on = cfg_scale != 1.0f;
+        if (cfg_on ? (B != 2 * batch) : (B != batch))
+            return mkd_fail(MKD_ERR_ARG, "mkd_sample: prepared batch must be B (cfg_scale == 1) or 2B (uncond first)");
+        if (n_steps <= 0 || !timesteps || !alphas || !alphas_prev || !s1m || !x_T || !x_out)
+            return mkd_fail(MKD_ERR_ARG, "mkd_sample: bad arguments");
+        const int64_t n = (int64_t)batch * cfg.in_channels * h * w;
+        MKD_HIP_CHECK(hipMemcpyAsync(s_xa, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        float* xa = s_xa; float* xb = s_xb;
+        for (int i = 0; i < n_steps; ++i) {
+            const int index = n_steps - 1 - i;
+            int rc = launch_fill_i64(s_t, timesteps[index], B, stream); if (rc) return rc;
+            const float* ec; const float* eu = nullptr;
+            if (cfg_on) {
+                rc = launch_repeat_batch(xa, s_xin, n, 2, stream); if (rc) return rc;
+                rc = eps(s_xin, s_t, s_eps, stream); if (rc) return rc;
+                eu = s_eps; ec = s_eps + n;
+            } else {
+                rc = eps(xa, s_t, s_eps, stream); if (rc) return rc;
+                ec = s_eps;
+            }
+            rc = launch_ddim_step(xa, ec, eu, cfg_scale, alphas[index], alphas_prev[index], 0.f, s1m[index], nullptr, 1.f,
+                                  xb, nullptr, n, stream);
+            if (rc) return rc;
+            float* tmp = xa; xa = xb; xb = tmp;
+        }
+        MKD_HIP_CHECK(hipMemcpyAsync(x_out, xa, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return 0;
+    }
+
+    int64_t device_bytes() const {
+        return weight_bytes + (int64_t)persist_cap + (int64_t)temp_cap + (int64_t)splitk_ws_bytes + (int64_t)gn_ws_bytes;
+    }
+
+    ~mkd_ctx() {
+        for (void* p : owned) hipFree(p);
+        for (void* p : {(void*)persist_base, (void*)temp_base, (void*)splitk_ws, (void*)gn_ws, (void*)s_xa, (void*)s_xb,
+                        (void*)s_xin, (void*)s_eps, (void*)s_t})
+            if (p) hipFree(p);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void mkd_set_error(const std::string& msg) { g_last_error = msg; }
+int mkd_fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+extern "C" {
+
+const char* mkd_last_error(void) { return g_last_error.c_str(); }
+int mkd_abi_version(void) { return 1; }
+
+int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
+    if (!cfg || !out) return mkd_fail(MKD_ERR_ARG, "mkd_ctx_create: null argument");
+    if (cfg->transformer_depth != 1) return mkd_fail(MKD_ERR_UNSUPPORTED, "only transformer_depth == 1 is supported");
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->n_attention_resolutions < 0 || cfg->n_attention_resolutions > 8)
+        return mkd_fail(MKD_ERR_ARG, "mkd_ctx_create: bad level / attention_resolutions count");
+    if (cfg->model_channels % 32) return mkd_fail(MKD_ERR_ARG, "model_channels must be a multiple of 32 (GroupNorm32)");
+    if ((cfg->model_channels / cfg->num_heads) % 8) return mkd_fail(MKD_ERR_UNSUPPORTED, "head dim must be a multiple of 8");
+    if (cfg->context_dim % 8) return mkd_fail(MKD_ERR_UNSUPPORTED, "context_dim must be a multiple of 8");
+    for (int j = 0; j < 7; ++j)
+        if (cfg->hint_widths[j] % 8) return mkd_fail(MKD_ERR_UNSUPPORTED, "hint widths must be multiples of 8");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mkd_fail(MKD_ERR_HIP, "no HIP device visible: libmkd has no CPU path");
+    mkd_ctx* c = new mkd_ctx();
+    c->cfg = *cfg;
+    c->build_param_spec();
+    *out = c;
+    return 0;
+}
+
+void mkd_ctx_destroy(mkd_ctx* ctx) { delete ctx; }
+
+int mkd_load_weight(mkd_ctx* ctx, const char* name, const float* data, int ndim, const int64_t* shape) {
+    if (!ctx || !name || !data || !shape) return mkd_fail(MKD_ERR_ARG, "mkd_load_weight: null argument");
+    return ctx->load_weight(name, data, ndim, shape);
+}
+int mkd_weights_finalize(mkd_ctx* ctx) { return ctx ? ctx->finalize() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
+
+int64_t mkd_param_count(const mkd_ctx* ctx, int which) {
+    if (!ctx) return -1;
+    int64_t n = 0;
+    for (auto& kv : ctx->params) if (kv.second.which == which) n += kv.second.numel();
+    return n;
+}
+
+int mkd_param_total(const mkd_ctx* ctx) { return ctx ? (int)ctx->params.size() : -1; }
+const char* mkd_param_name(const mkd_ctx* ctx, int index) {
+    if (!ctx || index < 0 || index >= (int)ctx->params.size()) return nullptr;
+    auto it = ctx->params.begin();
+    std::advance(it, index);
+    return it->first.c_str();
+}
+int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4) {
+    if (!ctx || !shape4 || index < 0 || index >= (int)ctx->params.size()) return -1;
+    auto it = ctx->params.begin();
+    std::advance(it, index);
+    for (size_t i = 0; i < it->second.shape.size(); ++i) shape4[i] = it->second.shape[i];
+    return (int)it->second.shape.size();
+}
+
+int mkd_prepare(mkd_ctx* ctx, int batch, int h, int w, const float* hint, const float* context,
+                const float* control_scales, int only_mid_control, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->prepare(batch, h, w, hint, context, control_scales, only_mid_control, (hipStream_t)stream);
+}
+int mkd_eps(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->eps(x, t, eps_out, (hipStream_t)stream);
+}
+int mkd_ddim_step(const float* x, const float* eps_c, const float* eps_u, float cfg_scale, float a_t, float a_prev,
+                  float sigma_t, float sqrt_one_minus_at, const float* noise, float temperature, float* x_prev,
+                  float* pred_x0, int64_t n, void* stream) {
+    if (!x || !eps_c || !x_prev) return mkd_fail(MKD_ERR_ARG, "mkd_ddim_step: null pointer");
+    return launch_ddim_step(x, eps_c, eps_u, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise, temperature, x_prev,
+                            pred_x0, n, (hipStream_t)stream);
+}
+int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
+               const float* alphas_prev, const float* sqrt_one_minus_alphas, float cfg_scale, float* x_out, int use_graph,
+               void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
+                       (hipStream_t)stream);
+}
+double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
+int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }
+int64_t mkd_device_bytes(const mkd_ctx* ctx) { return ctx ? ctx->device_bytes() : 0; }
+
+// ---- single-kernel entry points ----------------------------------------------------------------------
+static bf16_t* g_zero = nullptr;
+static float* g_ws = nullptr; static size_t g_ws_bytes = 0;
+static float* g_gn = nullptr; static size_t g_gn_bytes = 0;
+
+static int scratch(float** p, size_t* have, size_t need) {
+    if (*have >= need && *p) return 0;
+    if (*p) { hipDeviceSynchronize(); hipFree(*p); *p = nullptr; }
+    MKD_HIP_CHECK(hipMalloc((void**)p, need ? need : 256));
+    *have = need;
+    return 0;
+}
+
+int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
+                  int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,
+                  int N, int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up,
+                  int splitk, void* stream) {
+    if (!A || !W || !C) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_bf16: null pointer");
+    if (!g_zero) {
+        MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
+        MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));
+    }
+    if (conv3x3 && M != batch * Hout * Wout) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_bf16: M != batch*Hout*Wout");
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.rowbias = rowbias; a.ldrb = ldrb; a.rows_per_batch = rows_per_batch;
+    a.R = R; a.ldr = ldr; a.scale = scale; a.act = act; a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K;
+    a.conv = conv3x3 ? 1 : 0; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
+    a.zero = g_zero;
+    int s = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K);
+    int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    if (rc) return rc;
+    a.ws = g_ws; a.splitk = s;
+    return launch_gemm(a, (hipStream_t)stream);
+}
+int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,
+                  int ld_out, int batch, int hw, int C, int groups, void* stream) {
+    int rc = scratch(&g_gn, &g_gn_bytes, groupnorm_partials_bytes(batch, hw, groups));
+    if (rc) return rc;
+    return launch_groupnorm(x, ld_in, gamma, beta, eps, silu, y, ld_out, batch, hw, C, groups, g_gn, (hipStream_t)stream);
+}
+int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps, uint16_t* y, int rows, int d, void* stream) {
+    return launch_layernorm(x, gamma, beta, eps, y, rows, d, (hipStream_t)stream);
+}
+int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+                  int batch, int Tq, int Tk, int heads, int dh, float scale, void* stream) {
+    return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, batch, Tq, Tk, heads, dh, scale, (hipStream_t)stream);
+}
+int mkd_geglu(const uint16_t* x, uint16_t* y, int rows, int inner, void* stream) {
+    return launch_geglu(x, y, rows, inner, (hipStream_t)stream);
+}
+int mkd_conv3x3_direct(const void* x, int in_nchw_f32, const uint16_t* w, const float* bias, void* y, int out_nchw_f32, int act,
+                       const uint16_t* add, int batch, int Hin, int Win, int Cin, int Cout, int stride, void* stream) {
+    return launch_conv3x3_direct(x, in_nchw_f32, w, bias, y, out_nchw_f32, act, add, batch, Hin, Win, Cin, Cout, stride,
+                                 (hipStream_t)stream);
+}
+int mkd_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int kh, int kw, void* stream) {
+    return launch_pack_conv_weight(w, out, Cout, Cin, kh, kw, (hipStream_t)stream);
+}
+
+}  // extern "C"

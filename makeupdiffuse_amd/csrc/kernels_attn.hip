@@ -1,0 +1,208 @@
+// softmax(Q K^T * scale) V per (sample, head) on the matrix cores, flash-style (no T x T matrix in HBM).
+// Replaces CrossAttention.forward's einsum / softmax / einsum for attn1 (self,
+// 16..4096 tokens) and attn2 (cross, 77 context tokens), reached from diffmk/makeup_diffuse.py:164-168.
+//
+// One workgroup = 4 wavefronts = 64 queries of one (sample, head); each wave owns 16 queries.
+// K/V tiles of 64 keys are staged through LDS (K row-major, V transposed so PV's operand is a pair of
+// 8-byte reads).  The score product is computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_16x16x32_bf16)
+// so a lane owns ONE query column: the softmax row-reduction is 15 in-register max/sum ops + two
+// cross-lane shuffles, and S^T's accumulator registers are, after a bf16 pack, directly the B
+// operand of O^T += V^T P^T (k-order permuted identically in both operands) - P never touches LDS.
+// Head dims 40 / 80 / 160 are zero-padded to the 32-deep MFMA K step inside LDS only.
+#include "mkd_common.h"
+
+namespace {
+
+constexpr int KT = 64;            // keys per tile
+
+template <int DH>
+struct AttnCfg {
+    static constexpr int DHP = (DH + 31) / 32 * 32;      // QK^T contraction depth (padded)
+    static constexpr int KS = DHP / 32;                  // k-steps of QK^T
+    static constexpr int DVP = (DH + 15) / 16 * 16;      // output rows of O^T (padded)
+    static constexpr int MD = DVP / 16;                  // O^T fragments
+    static constexpr int KROW = DHP * 2 + 16;            // K tile row stride in bytes (pad: bank spread)
+    static constexpr int VROW = KT * 2 + 8;              // V^T tile row stride in bytes
+    static constexpr int KBYTES = KT * KROW;
+    static constexpr int VBYTES = DVP * VROW;
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                        const bf16_t* __restrict__ K, int ldk,
+                                                        const bf16_t* __restrict__ V, int ldv,
+                                                        bf16_t* __restrict__ O, int ldo,
+                                                        int Tq, int Tk, int heads, float scale_log2e) {
+    using C = AttnCfg<DH>;
+    __shared__ __attribute__((aligned(16))) char smem[C::KBYTES + C::VBYTES];
+    char* ks = smem;
+    char* vs = smem + C::KBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int qc = lane & 15;          // query column owned by this lane
+    const int g = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / heads, h = bh - b * heads;
+    const int q0 = blockIdx.x * 64 + w * 16;
+    const int qi = q0 + qc;
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds Q[qi][32*ks + 8*g + j]
+    bf16x8 qf[C::KS];
+    {
+        const bf16_t* qrow = Q + ((size_t)b * Tq + (qi < Tq ? qi : 0)) * ldq + h * DH;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const int d = 32 * s + 8 * g;
+            U16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.v[j] = 0;
+            if (qi < Tq && d < DH) t = *(const U16x8*)(qrow + d);
+            qf[s] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+
+    f32x4 oacc[C::MD];
+#pragma unroll
+    for (int i = 0; i < C::MD; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const bf16_t* kbase = K + (size_t)b * Tk * ldk + h * DH;
+    const bf16_t* vbase = V + (size_t)b * Tk * ldv + h * DH;
+    const int ntiles = (Tk + KT - 1) / KT;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        __syncthreads();                                   // previous tile fully consumed
+        // ---- stage K tile [64][DHP] row-major (zero padded) ------------------------------------
+        for (int idx = tid; idx < KT * (C::DHP / 8); idx += 256) {
+            const int r = idx / (C::DHP / 8);
+            const int c = idx - r * (C::DHP / 8);
+            U16x8 d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d.v[j] = 0;
+            if (key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(kbase + (size_t)(key0 + r) * ldk + c * 8);
+            *(U16x8*)(ks + r * C::KROW + c * 16) = d;
+        }
+        // ---- stage V tile transposed: vs[d][key] -------------------------------------------------
+        for (int idx = tid; idx < KT * (C::DVP / 8); idx += 256) {
+            const int c = idx / KT;                         // d-chunk (8 values)
+            const int r = idx - c * KT;                     // key: consecutive lanes -> consecutive keys
+            U16x8 d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d.v[j] = 0;
+            if (key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(vbase + (size_t)(key0 + r) * ldv + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(uint16_t*)(vs + (c * 8 + j) * C::VROW + r * 2) = d.v[j];
+        }
+        __syncthreads();
+
+        // ---- S^T[key][q] for 4 key blocks of 16 -------------------------------------------------
+        f32x4 st[4];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(ks + (16 * mf + qc) * C::KROW + (32 * s + 8 * g) * 2);
+                st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[mf], 0, 0, 0);
+            }
+        }
+        // lane holds scores of query qc for keys key0 + 16*mf + 4*g + r
+        float mx = -INFINITY;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + 16 * mf + 4 * g + r;
+                float s = st[mf][r] * scale_log2e;
+                s = key < Tk ? s : -INFINITY;
+                st[mf][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);              // finite: every tile has >= 1 valid key
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = exp2f(st[mf][r] - m_new);
+                st[mf][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
+
+        // ---- O^T[d][q] += V^T[d][key'] P^T[key'][q]; key'(g, j) = 32*s + (j<4 ? 4g+j : 16+4g+j-4) -----
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (__bf16)st[2 * s][j];
+                pf[4 + j] = (__bf16)st[2 * s + 1][j];
+            }
+#pragma unroll
+            for (int md = 0; md < C::MD; ++md) {
+                const char* vrow = vs + (16 * md + qc) * C::VROW;
+                const bf16x4 lo = *(const bf16x4*)(vrow + (32 * s + 4 * g) * 2);
+                const bf16x4 hi = *(const bf16x4*)(vrow + (32 * s + 16 + 4 * g) * 2);
+                bf16x8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                oacc[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[md], 0, 0, 0);
+            }
+        }
+    }
+
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    if (qi < Tq) {
+        bf16_t* orow = O + ((size_t)b * Tq + qi) * ldo + h * DH;
+#pragma unroll
+        for (int md = 0; md < C::MD; ++md) {
+            const int d = 16 * md + 4 * g;
+            if (d < DH) {
+                U16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.v[r] = f32_to_bf16(oacc[md][r] * inv);
+                *(U16x4*)(orow + d) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
+                     bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
+                     hipStream_t stream) {
+    if (Tq <= 0 || Tk <= 0 || batch <= 0 || heads <= 0) return mkd_fail(-1, "attention: empty problem");
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
+    dim3 grid((Tq + 63) / 64, batch * heads);
+    const float sl = scale * 1.4426950408889634f;
+#define MKD_ATTN_CASE(D)                                                                                   \
+    case D:                                                                                                \
+        hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo, \
+                           Tq, Tk, heads, sl);                                                             \
+        break;
+    switch (dh) {
+        MKD_ATTN_CASE(8)
+        MKD_ATTN_CASE(16)
+        MKD_ATTN_CASE(32)
+        MKD_ATTN_CASE(40)
+        MKD_ATTN_CASE(64)
+        MKD_ATTN_CASE(80)
+        MKD_ATTN_CASE(160)
+        default:
+            return mkd_fail(-4, "attention: unsupported head dim " + std::to_string(dh));
+    }
+#undef MKD_ATTN_CASE
+    MKD_LAUNCH_CHECK("attention_kernel");
+    return 0;
+}

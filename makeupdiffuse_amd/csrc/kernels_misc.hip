@@ -1,0 +1,216 @@
+// Small HBM-bound kernels of the path: DDIM update (+CFG combine), GEGLU, sinusoidal timestep
+// embedding, the three tiny-channel 3x3 convs (4->C, 6->16, C->4), weight packing, layout glue.
+#include "mkd_common.h"
+
+namespace {
+
+// ---- DDIM x0 / x_{t-1} update, reference diffmk/cddim.py:39-40 (CFG) and :63,74-78 ----------------
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                 const float* __restrict__ eps_u, float cfg_scale, float sqrt_at_inv,
+                                 float sqrt_aprev, float dir_coef, float sigma_t, float s1m,
+                                 const float* __restrict__ noise, float temperature,
+                                 float* __restrict__ x_prev, float* __restrict__ pred_x0, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e = eps_c[i];
+        if (eps_u) {
+            const float u = eps_u[i];
+            e = u + cfg_scale * (e - u);            // model_uncond + s * (model_t - model_uncond)
+        }
+        const float xv = x[i];
+        const float p0 = (xv - s1m * e) * sqrt_at_inv;   // (x - sqrt(1-a_t) e) / sqrt(a_t)
+        float xp = sqrt_aprev * p0 + dir_coef * e;       // sqrt(a_prev) x0 + sqrt(1-a_prev-sigma^2) e
+        if (noise) xp += sigma_t * noise[i] * temperature;
+        x_prev[i] = xp;
+        if (pred_x0) pred_x0[i] = p0;
+    }
+}
+
+// ---- GEGLU: y = a * gelu_erf(gate) ----------------------------------------------------------------
+__global__ void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int rows, int inner) {
+    const int vper = inner >> 3;
+    const int64_t total = (int64_t)rows * vper;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / vper);
+        const int c = (int)(idx - (int64_t)r * vper) << 3;
+        const U16x8 a = *(const U16x8*)(x + (size_t)r * 2 * inner + c);
+        const U16x8 gt = *(const U16x8*)(x + (size_t)r * 2 * inner + inner + c);
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = f32_to_bf16(bf16_to_f32(a.v[j]) * gelu_erf_f(bf16_to_f32(gt.v[j])));
+        *(U16x8*)(y + (size_t)r * inner + c) = o;
+    }
+}
+
+// ---- sinusoidal timestep embedding: out[b] = [cos(t f_k), sin(t f_k)], f_k = exp(-ln(1e4) k / half) --
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, bf16_t* __restrict__ out, int batch, int dim) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * half) return;
+    const int b = idx / half, k = idx - b * half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = (float)t[b] * freq;
+    out[(size_t)b * dim + k] = f32_to_bf16(cosf(a));
+    out[(size_t)b * dim + half + k] = f32_to_bf16(sinf(a));
+}
+
+// ---- direct 3x3 conv (pad 1), one thread per output element, fp32 accumulate ----------------------
+// Only used where the channel count is too small for the MFMA path (Cin 4/6, or Cout 4).
+__global__ void conv3x3_direct_kernel(const void* __restrict__ xin, int in_nchw_f32, const bf16_t* __restrict__ w,
+                                      const float* __restrict__ bias, void* __restrict__ yout, int out_nchw_f32,
+                                      int act, const bf16_t* __restrict__ add, int batch, int Hin, int Win,
+                                      int Cin, int Cout, int Hout, int Wout, int stride) {
+    const int64_t total = (int64_t)batch * Hout * Wout * Cout;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        int64_t pix = idx / Cout;
+        const int ox = (int)(pix % Wout); pix /= Wout;
+        const int oy = (int)(pix % Hout);
+        const int b = (int)(pix / Hout);
+        float acc = bias ? bias[co] : 0.f;
+        const bf16_t* wr = w + (size_t)co * 9 * Cin;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride + ky - 1;
+            if ((unsigned)iy >= (unsigned)Hin) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride + kx - 1;
+                if ((unsigned)ix >= (unsigned)Win) continue;
+                const bf16_t* wt = wr + (ky * 3 + kx) * Cin;
+                if (in_nchw_f32) {
+                    const float* xp = (const float*)xin + ((size_t)b * Cin * Hin + iy) * Win + ix;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        acc += xp[(size_t)ci * Hin * Win] * bf16_to_f32(wt[ci]);
+                } else {
+                    const bf16_t* xp = (const bf16_t*)xin + ((size_t)(b * Hin + iy) * Win + ix) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) acc += bf16_to_f32(xp[ci]) * bf16_to_f32(wt[ci]);
+                }
+            }
+        }
+        if (act == 1) acc = silu_f(acc);
+        const size_t opix = ((size_t)b * Hout + oy) * Wout + ox;
+        if (add) acc += bf16_to_f32(add[opix * Cout + co]);
+        if (out_nchw_f32) ((float*)yout)[(((size_t)b * Cout + co) * Hout + oy) * Wout + ox] = acc;
+        else ((bf16_t*)yout)[opix * Cout + co] = f32_to_bf16(acc);
+    }
+}
+
+// ---- fp32 [Cout,Cin,kh,kw] -> bf16 [Cout][kh][kw][Cin] ----------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int kh, int kw) {
+    const int64_t total = (int64_t)Cout * Cin * kh * kw;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin);
+        int64_t r = idx / Cin;
+        const int x = (int)(r % kw); r /= kw;
+        const int y = (int)(r % kh);
+        const int co = (int)(r / kh);
+        out[idx] = f32_to_bf16(w[(((size_t)co * Cin + ci) * kh + y) * kw + x]);
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = f32_to_bf16(x[i]);
+}
+
+__global__ void copy_strided_kernel(const bf16_t* __restrict__ src, int ld_src, bf16_t* __restrict__ dst, int ld_dst,
+                                    int rows, int cols) {
+    const int vper = cols >> 3;
+    const int64_t total = (int64_t)rows * vper;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / vper);
+        const int c = (int)(idx - (int64_t)r * vper) << 3;
+        *(U16x8*)(dst + (size_t)r * ld_dst + c) = *(const U16x8*)(src + (size_t)r * ld_src + c);
+    }
+}
+
+__global__ void repeat_batch_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_per, int reps) {
+    const int64_t total = n_per * reps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i % n_per];
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+inline int grid_for(int64_t total, int block = 256, int cap = 2048) {
+    int64_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+int launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, float cfg_scale, float a_t,
+                     float a_prev, float sigma_t, float s1m, const float* noise, float temperature,
+                     float* x_prev, float* pred_x0, int64_t n, hipStream_t stream) {
+    if (n <= 0) return mkd_fail(-1, "ddim_step: empty");
+    const float sqrt_at_inv = 1.0f / sqrtf(a_t);
+    const float sqrt_aprev = sqrtf(a_prev);
+    const float dir_coef = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, cfg_scale,
+                       sqrt_at_inv, sqrt_aprev, dir_coef, sigma_t, s1m, noise, temperature, x_prev, pred_x0, n);
+    MKD_LAUNCH_CHECK("ddim_step_kernel");
+    return 0;
+}
+
+int launch_geglu(const bf16_t* x, bf16_t* y, int rows, int inner, hipStream_t stream) {
+    if (inner % 8) return mkd_fail(-1, "geglu: inner must be a multiple of 8");
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((int64_t)rows * (inner / 8), 256, 4096)), dim3(256), 0, stream, x, y, rows, inner);
+    MKD_LAUNCH_CHECK("geglu_kernel");
+    return 0;
+}
+
+int launch_timestep_embedding(const int64_t* t, bf16_t* out, int batch, int dim, hipStream_t stream) {
+    if (dim % 2) return mkd_fail(-1, "timestep_embedding: odd dim");
+    const int total = batch * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, out, batch, dim);
+    MKD_LAUNCH_CHECK("timestep_embedding_kernel");
+    return 0;
+}
+
+int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
+                          int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
+                          int Cin, int Cout, int stride, hipStream_t stream) {
+    if (stride != 1 && stride != 2) return mkd_fail(-1, "conv3x3_direct: stride must be 1 or 2");
+    const int Hout = (Hin + 2 - 3) / stride + 1, Wout = (Win + 2 - 3) / stride + 1;
+    const int64_t total = (int64_t)batch * Hout * Wout * Cout;
+    hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, stream, x, in_nchw_f32, w, bias,
+                       y, out_nchw_f32, act, add, batch, Hin, Win, Cin, Cout, Hout, Wout, stride);
+    MKD_LAUNCH_CHECK("conv3x3_direct_kernel");
+    return 0;
+}
+
+int launch_pack_conv_weight(const float* w, bf16_t* out, int Cout, int Cin, int kh, int kw, hipStream_t stream) {
+    const int64_t total = (int64_t)Cout * Cin * kh * kw;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, w, out, Cout, Cin, kh, kw);
+    MKD_LAUNCH_CHECK("pack_conv_weight_kernel");
+    return 0;
+}
+
+int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n);
+    MKD_LAUNCH_CHECK("f32_to_bf16_kernel");
+    return 0;
+}
+
+int launch_copy_strided(const bf16_t* src, int ld_src, bf16_t* dst, int ld_dst, int rows, int cols, hipStream_t stream) {
+    if (cols % 8 || ld_src % 8 || ld_dst % 8) return mkd_fail(-1, "copy_strided: multiples of 8 required");
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((int64_t)rows * (cols / 8))), dim3(256), 0, stream, src, ld_src, dst,
+                       ld_dst, rows, cols);
+    MKD_LAUNCH_CHECK("copy_strided_kernel");
+    return 0;
+}
+
+int launch_repeat_batch(const float* x, float* y, int64_t n_per, int reps, hipStream_t stream) {
+    hipLaunchKernelGGL(repeat_batch_kernel, dim3(grid_for(n_per * reps)), dim3(256), 0, stream, x, y, n_per, reps);
+    MKD_LAUNCH_CHECK("repeat_batch_kernel");
+    return 0;
+}
+
+int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+    MKD_LAUNCH_CHECK("fill_i64_kernel");
+    return 0;
+}

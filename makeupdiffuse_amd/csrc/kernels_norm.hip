@@ -1,0 +1,212 @@
+// GroupNorm(32)[+SiLU] and LayerNorm over NHWC bf16 (HBM-bound kernels, fp32 statistics).
+// Replaces cldm GroupNorm32 -> SiLU in ResBlock.in_layers/out_layers, SpatialTransformer.norm and
+// BasicTransformerBlock.norm1-3, reached from diffmk/makeup_diffuse.py:164-168.
+//
+// GroupNorm: a sample's statistics span all pixels, so it is two passes over a tensor that is
+// L2/Infinity-Cache resident: (1) per-(sample, pixel-chunk) partial sum/sumsq per group, every
+// thread owning a FIXED 8-channel vector so sums stay in registers, 16-B coalesced loads;
+// (2) fold partials -> mean/rstd, apply gamma/beta (+SiLU), 16-B stores.
+// LayerNorm: one 64-lane wavefront per row, row kept in registers, wave-shuffle reductions.
+#include "mkd_common.h"
+
+namespace {
+
+constexpr int GN_MAX_GROUPS = 32;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// threads = V * P where V = C/8 vectors per pixel (thread's vector id = tid % V, fixed).
+__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, int ld, int hw, int C, int groups,
+                                int rows_per_chunk, float* __restrict__ partials) {
+    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    const int V = C >> 3;
+    const int T = blockDim.x;
+    const int P = T / V;
+    const int tid = threadIdx.x;
+    const int v = tid % V;
+    const int pl = tid / V;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(hw, r0 + rows_per_chunk);
+    if (tid < groups) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+    __syncthreads();
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
+    const bf16_t* base = x + (size_t)b * hw * ld + v * 8;
+    for (int r = r0 + pl; r < r1; r += P) {
+        const U16x8 d = *(const U16x8*)(base + (size_t)r * ld);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf16_to_f32(d.v[j]);
+            sum[j] += f; sq[j] += f * f;
+        }
+    }
+    const int cg = C / groups;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (v * 8 + j) / cg;
+        atomicAdd(&s_sum[g], sum[j]);
+        atomicAdd(&s_sq[g], sq[j]);
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float* o = partials + ((size_t)(b * gridDim.x + chunk) * groups + tid) * 2;
+        o[0] = s_sum[tid]; o[1] = s_sq[tid];
+    }
+}
+
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y, int ld_out,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                int silu, int hw, int C, int groups, int rows_per_chunk, int nchunks,
+                                const float* __restrict__ partials) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    const int V = C >> 3;
+    const int T = blockDim.x;
+    const int P = T / V;
+    const int tid = threadIdx.x;
+    const int v = tid % V;
+    const int pl = tid / V;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (tid < groups) {
+        float s = 0.f, q = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            const float* pp = partials + ((size_t)(b * nchunks + c) * groups + tid) * 2;
+            s += pp[0]; q += pp[1];
+        }
+        const float n = (float)hw * (float)(C / groups);
+        const float mean = s / n;
+        float var = q / n - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int cg = C / groups;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        const int g = c / cg;
+        const float a = gamma[c] * s_rstd[g];
+        sa[j] = a;
+        sb[j] = beta[c] - s_mean[g] * a;
+    }
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(hw, r0 + rows_per_chunk);
+    const bf16_t* xin = x + (size_t)b * hw * ld_in + v * 8;
+    bf16_t* yout = y + (size_t)b * hw * ld_out + v * 8;
+    for (int r = r0 + pl; r < r1; r += P) {
+        const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf16_to_f32(d.v[j]) * sa[j] + sb[j];
+            if (silu) f = silu_f(f);
+            o.v[j] = f32_to_bf16(f);
+        }
+        *(U16x8*)(yout + (size_t)r * ld_out) = o;
+    }
+}
+
+// one wave per row; NV = vectors of 8 per lane (d <= 64*8*NV)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        bf16_t* __restrict__ y, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int V = d >> 3;
+    float f[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+            const U16x8 t = *(const U16x8*)(x + (size_t)row * d + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f[i][j] = bf16_to_f32(t.v[j]); s += f[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float c = f[i][j] - mean; q += c * c; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+            U16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = v * 8 + j;
+                o.v[j] = f32_to_bf16((f[i][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *(U16x8*)(y + (size_t)row * d + v * 8) = o;
+        }
+    }
+}
+
+int gn_chunks(int hw) {
+    int n = hw / 16;              // >= 16 pixels per chunk
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+}  // namespace
+
+size_t groupnorm_partials_bytes(int batch, int hw, int groups) {
+    return (size_t)batch * gn_chunks(hw) * groups * 2 * sizeof(float);
+}
+
+int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
+                     bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
+                     hipStream_t stream) {
+    if (C % 8 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C, ld must be multiples of 8");
+    if (groups > GN_MAX_GROUPS || groups <= 0 || C % groups) return mkd_fail(-1, "groupnorm: bad group count");
+    if (!partials) return mkd_fail(-1, "groupnorm: partials workspace missing");
+    const int V = C / 8;
+    if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");
+    int P = 256 / V;
+    if (P < 1) P = 1;
+    const int threads = V * P;
+    const int nchunks = gn_chunks(hw);
+    const int rows_per_chunk = (hw + nchunks - 1) / nchunks;
+    dim3 grid(nchunks, batch);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 0, stream, x, ld_in, hw, C, groups, rows_per_chunk, partials);
+    MKD_LAUNCH_CHECK("gn_stats_kernel");
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
+                       hw, C, groups, rows_per_chunk, nchunks, partials);
+    MKD_LAUNCH_CHECK("gn_apply_kernel");
+    return 0;
+}
+
+int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
+                     int rows, int d, hipStream_t stream) {
+    if (d % 8) return mkd_fail(-1, "layernorm: d must be a multiple of 8");
+    const int V = d / 8;
+    dim3 grid((rows + 3) / 4);
+    if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
+    else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
+    else if (V <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
+    else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
+    else return mkd_fail(-4, "layernorm: d > 2048 unsupported");
+    MKD_LAUNCH_CHECK("layernorm_kernel");
+    return 0;
+}

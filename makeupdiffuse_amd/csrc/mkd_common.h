@@ -1,0 +1,93 @@
+// Shared declarations for libmkd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;   // raw bf16 bits on the host side of the launchers
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void mkd_set_error(const std::string& msg);
+int mkd_fail(int code, const std::string& msg);
+
+#define MKD_HIP_CHECK(expr)                                                            \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return mkd_fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+#define MKD_LAUNCH_CHECK(what)                                                         \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess)                                                          \
+            return mkd_fail(-2, std::string(what) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even via the hardware convert (keeps NaN a NaN).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+struct __attribute__((aligned(16))) U16x8 { uint16_t v[8]; };
+struct __attribute__((aligned(8)))  U16x4 { uint16_t v[4]; };
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// kernel launch parameter blocks (host + device)
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const float* bias;
+    const float* rowbias; int ldrb; int rows_per_batch;
+    const bf16_t* R; int ldr;
+    float scale; int act;
+    void* C; int ldc; int out_f32;
+    int M, N, K;
+    int conv; int Hin, Win, Cin, Hout, Wout, stride, up;
+    float* ws; int splitk; int ksteps_per_split;
+    const bf16_t* zero;   // >= 16 bytes of zeros
+};
+
+// launchers (each only enqueues on `stream`)
+int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
+int  gemm_pick_splitk(int M, int N, int K);
+size_t gemm_ws_bytes(int M, int N, int splitk);
+
+int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
+                     bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
+                     hipStream_t stream);
+size_t groupnorm_partials_bytes(int batch, int hw, int groups);
+int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
+                     int rows, int d, hipStream_t stream);
+int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
+                     bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
+                     hipStream_t stream);
+int launch_geglu(const bf16_t* x, bf16_t* y, int rows, int inner, hipStream_t stream);
+int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
+                          int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
+                          int Cin, int Cout, int stride, hipStream_t stream);
+int launch_pack_conv_weight(const float* w, bf16_t* out, int Cout, int Cin, int kh, int kw, hipStream_t stream);
+int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t stream);
+int launch_timestep_embedding(const int64_t* t, bf16_t* out, int batch, int dim, hipStream_t stream);
+int launch_copy_strided(const bf16_t* src, int ld_src, bf16_t* dst, int ld_dst, int rows, int cols,
+                        hipStream_t stream);
+int launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, float cfg_scale, float a_t,
+                     float a_prev, float sigma_t, float s1m, const float* noise, float temperature,
+                     float* x_prev, float* pred_x0, int64_t n, hipStream_t stream);
+int launch_repeat_batch(const float* x, float* y, int64_t n_per, int reps, hipStream_t stream);
+int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);

@@ -1,0 +1,263 @@
+"""Python host wrapper of the libmkd engine (plumbing: torch supplies device memory and the stream).
+
+``MkdEngine`` is what ``diffmk.makeup_diffuse`` model classes delegate ``apply_model`` / ``sample_log``
+to.  Everything here fails loudly without a GPU or without libmkd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+@dataclass
+class NetConfig:
+    """control_stage_config / unet_config params of diffmodels/base_diffusion_makeup.yaml:52-84."""
+    in_channels: int = 4
+    out_channels: int = 4
+    hint_channels: int = 6
+    model_channels: int = 320
+    attention_resolutions: Sequence[int] = (4, 2, 1)
+    num_res_blocks: int = 2
+    channel_mult: Sequence[int] = (1, 2, 4, 4)
+    num_heads: int = 8
+    transformer_depth: int = 1
+    context_dim: int = 768
+    hint_widths: Sequence[int] = (16, 16, 32, 32, 96, 96, 256)
+
+    @classmethod
+    def from_yaml_params(cls, control: dict, unet: dict) -> 'NetConfig':
+        for k in ('model_channels', 'attention_resolutions', 'num_res_blocks', 'channel_mult', 'num_heads',
+                  'transformer_depth', 'context_dim', 'in_channels'):
+            if k in control and k in unet and list(np.atleast_1d(control[k])) != list(np.atleast_1d(unet[k])):
+                raise ValueError(f'control_stage_config and unet_config disagree on {k}')
+        if not unet.get('use_spatial_transformer', True) or unet.get('legacy', False):
+            raise NotImplementedError('only use_spatial_transformer=True, legacy=False is supported')
+        return cls(in_channels=unet.get('in_channels', 4), out_channels=unet.get('out_channels', 4),
+                   hint_channels=control.get('hint_channels', 6), model_channels=unet['model_channels'],
+                   attention_resolutions=tuple(unet['attention_resolutions']),
+                   num_res_blocks=unet['num_res_blocks'], channel_mult=tuple(unet['channel_mult']),
+                   num_heads=unet['num_heads'], transformer_depth=unet.get('transformer_depth', 1),
+                   context_dim=unet['context_dim'],
+                   hint_widths=tuple(control.get('hint_widths', (16, 16, 32, 32, 96, 96, 256))))
+
+    def to_c(self) -> _lib.NetConfigC:
+        c = _lib.NetConfigC()
+        c.in_channels, c.out_channels, c.hint_channels = self.in_channels, self.out_channels, self.hint_channels
+        c.model_channels, c.num_res_blocks = self.model_channels, self.num_res_blocks
+        c.n_levels = len(self.channel_mult)
+        for i, m in enumerate(self.channel_mult):
+            c.channel_mult[i] = m
+        c.n_attention_resolutions = len(self.attention_resolutions)
+        for i, a in enumerate(self.attention_resolutions):
+            c.attention_resolutions[i] = a
+        c.num_heads, c.transformer_depth, c.context_dim = self.num_heads, self.transformer_depth, self.context_dim
+        for i, hw in enumerate(self.hint_widths):
+            c.hint_widths[i] = hw
+        return c
+
+    @property
+    def n_control(self) -> int:
+        n = 1
+        for level in range(len(self.channel_mult)):
+            n += self.num_res_blocks + (1 if level != len(self.channel_mult) - 1 else 0)
+        return n + 1
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class MkdEngine:
+    """Owns one mkd_ctx on the current CUDA(HIP) device."""
+
+    UNET_PREFIX = 'model.diffusion_model.'
+    CONTROL_PREFIX = 'control_model.'
+
+    def __init__(self, cfg: NetConfig, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise _lib.MkdError('MkdEngine needs a HIP device: the hot path has no CPU implementation')
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_ctx_create(C.byref(cfg.to_c()), C.byref(self._ctx)), 'mkd_ctx_create')
+        self._keep: list = []          # tensors the prepared plan points at
+        self._prepared_key = None
+        self.batch = 0
+        self.latent_hw: Tuple[int, int] = (0, 0)
+
+    def close(self):
+        if self._ctx:
+            self.lib.mkd_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def expected_params(self) -> Dict[str, Tuple[int, ...]]:
+        n = self.lib.mkd_param_total(self._ctx)
+        out = {}
+        shp = (C.c_int64 * 4)()
+        for i in range(n):
+            name = self.lib.mkd_param_name(self._ctx, i).decode()
+            nd = self.lib.mkd_param_shape(self._ctx, i, shp)
+            out[name] = tuple(int(shp[j]) for j in range(nd))
+        return out
+
+    def param_count(self, which: str) -> int:
+        return int(self.lib.mkd_param_count(self._ctx, 0 if which == 'unet' else 1))
+
+    def load_weight(self, name: str, tensor: torch.Tensor) -> None:
+        t = tensor.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+        with torch.cuda.device(self.device):
+            if t.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            _lib.check(self.lib.mkd_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), shape),
+                       f'mkd_load_weight({name})')
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> List[str]:
+        """Loads every key under model.diffusion_model. / control_model. (upstream names); other keys
+        (first_stage_model.*, cond_stage_model.*, teacher_model*) are returned as 'unused'."""
+        expected = self.expected_params()
+        unused = []
+        for k, v in sd.items():
+            if k in expected:
+                self.load_weight(k, v)
+            else:
+                unused.append(k)
+        missing = [k for k in expected if k not in sd]
+        if missing and strict:
+            raise _lib.MkdError(f'{len(missing)} weights missing from state_dict, e.g. {missing[:3]}')
+        if not missing:
+            self.finalize()
+        return unused
+
+    def init_random(self, seed: int = 0, gain: float = 1.0) -> None:
+        """Seeded synthetic weights generated ON the device (bench only): N(0, 1/fan_in) for
+        every matrix/conv including upstream's zero-initialised ones, gamma 1 / beta 0, small biases."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        for name, shape in self.expected_params().items():
+            is_norm = ('.norm' in name or 'in_layers.0' in name or 'out_layers.0' in name
+                       or name.endswith('out.0.weight') or name.endswith('out.0.bias'))
+            if len(shape) == 1:
+                if is_norm:
+                    t = (torch.ones if name.endswith('weight') else torch.zeros)(shape, device=self.device)
+                else:
+                    t = 0.02 * torch.randn(shape, generator=g, device=self.device)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                t = (gain / fan_in ** 0.5) * torch.randn(shape, generator=g, device=self.device)
+            self.load_weight(name, t)
+        self.finalize()
+
+    def finalize(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_weights_finalize(self._ctx), 'mkd_weights_finalize')
+
+    # ---- conditioning / eval -----------------------------------------------------------------------
+    def prepare(self, hint: Optional[torch.Tensor], context: torch.Tensor, latent_hw: Optional[Tuple[int, int]] = None,
+                control_scales: Optional[Sequence[float]] = None, only_mid_control: bool = False) -> None:
+        """hint [B,6,8h,8w] in [0,1] or None (c_concat is None); context [B,77,ctx_dim]."""
+        B = context.shape[0]
+        ctx = _f32c(context, self.device)
+        if ctx.shape[1] != 77 or ctx.shape[2] != self.cfg.context_dim:
+            raise ValueError(f'context must be [B,77,{self.cfg.context_dim}], got {tuple(ctx.shape)}')
+        hint_t = None
+        if hint is not None:
+            hint_t = _f32c(hint, self.device)
+            if hint_t.shape[0] != B or hint_t.shape[1] != self.cfg.hint_channels or hint_t.shape[2] % 8 or hint_t.shape[3] % 8:
+                raise ValueError(f'hint must be [B,{self.cfg.hint_channels},8h,8w], got {tuple(hint_t.shape)}')
+            h, w = hint_t.shape[2] // 8, hint_t.shape[3] // 8
+            if latent_hw is not None and tuple(latent_hw) != (h, w):
+                raise ValueError('latent_hw disagrees with the hint size')
+        else:
+            if latent_hw is None:
+                raise ValueError('latent_hw is required when hint is None')
+            h, w = latent_hw
+        scales = None
+        if control_scales is not None:
+            if len(control_scales) != self.cfg.n_control:
+                raise ValueError(f'control_scales must have {self.cfg.n_control} entries')
+            scales = (C.c_float * len(control_scales))(*[float(s) for s in control_scales])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_prepare(self._ctx, B, h, w, C.c_void_p(_ptr(hint_t)), C.c_void_p(ctx.data_ptr()),
+                                            scales, int(bool(only_mid_control)), C.c_void_p(_stream())), 'mkd_prepare')
+        self._keep = [hint_t, ctx]
+        self.batch, self.latent_hw = B, (h, w)
+
+    def eps(self, x: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One apply_model evaluation on the prepared conditioning. x [B,4,h,w] fp32, t [B] int64."""
+        x = _f32c(x, self.device)
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        if tuple(x.shape) != (self.batch, self.cfg.in_channels, *self.latent_hw) or t.shape[0] != self.batch:
+            raise ValueError(f'x/t do not match the prepared batch {self.batch} x {self.latent_hw}: {tuple(x.shape)}')
+        if out is None:
+            out = torch.empty((self.batch, self.cfg.out_channels, *self.latent_hw), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_eps(self._ctx, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), 'mkd_eps')
+        return out
+
+    def ddim_step(self, x, eps_c, eps_u, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None,
+                  temperature: float = 1.0, want_x0: bool = True):
+        x = _f32c(x, self.device); eps_c = _f32c(eps_c, self.device)
+        eps_u = None if eps_u is None else _f32c(eps_u, self.device)
+        noise = None if noise is None else _f32c(noise, self.device)
+        x_prev = torch.empty_like(x)
+        x0 = torch.empty_like(x) if want_x0 else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_ddim_step(C.c_void_p(x.data_ptr()), C.c_void_p(eps_c.data_ptr()), C.c_void_p(_ptr(eps_u)),
+                                              float(cfg_scale), float(a_t), float(a_prev), float(sigma_t),
+                                              float(sqrt_one_minus_at), C.c_void_p(_ptr(noise)), float(temperature),
+                                              C.c_void_p(x_prev.data_ptr()), C.c_void_p(_ptr(x0)), x.numel(),
+                                              C.c_void_p(_stream())), 'mkd_ddim_step')
+        return x_prev, x0
+
+    def sample(self, x_T: torch.Tensor, timesteps: Sequence[int], alphas: Sequence[float], alphas_prev: Sequence[float],
+               sqrt_one_minus_alphas: Sequence[float], cfg_scale: float = 1.0, use_graph: bool = False) -> torch.Tensor:
+        """Whole eta=0 reverse loop in one call (cddim.py:81-100). Prepared batch must be B or 2B (CFG)."""
+        x_T = _f32c(x_T, self.device)
+        n = len(timesteps)
+        ts = (C.c_int64 * n)(*[int(v) for v in timesteps])
+        a = (C.c_float * n)(*[float(v) for v in alphas])
+        ap = (C.c_float * n)(*[float(v) for v in alphas_prev])
+        s1 = (C.c_float * n)(*[float(v) for v in sqrt_one_minus_alphas])
+        out = torch.empty_like(x_T)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_sample(self._ctx, C.c_void_p(x_T.data_ptr()), x_T.shape[0], n, ts, a, ap, s1,
+                                           float(cfg_scale), C.c_void_p(out.data_ptr()), int(use_graph),
+                                           C.c_void_p(_stream())), 'mkd_sample')
+        return out
+
+    # ---- introspection -----------------------------------------------------------------------------
+    def eps_flops(self) -> float:
+        return float(self.lib.mkd_eps_flops(self._ctx))
+
+    def eps_launches(self) -> int:
+        return int(self.lib.mkd_eps_launches(self._ctx))
+
+    def device_bytes(self) -> int:
+        return int(self.lib.mkd_device_bytes(self._ctx))

@@ -1,0 +1,129 @@
+"""-m gpu: the whole eps evaluation / DDIM loop through the C ABI vs the CPU oracle and the committed
+golden fixtures.  Tolerances are SURVEY.md §8c's: one eps eval rel-L2 <= 2e-2, cosine >= 0.9995;
+multi-step latents cosine >= 0.99 (bf16 compute, fp32 oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from makeupdiffuse_amd.engine import MkdEngine, NetConfig
+from oracle import nets, sampler
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SMALL = dict(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+             hint_widths=(16, 16, 32, 32, 32, 32, 64))
+
+
+def check_eps(out, ref, rel=2e-2, cos=0.9995, what=''):
+    out = out.float().cpu(); ref = ref.float().cpu()
+    assert torch.isfinite(out).all(), f'{what}: non-finite'
+    r = ((out - ref).norm() / ref.norm()).item()
+    c = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    assert r <= rel and c >= cos, f'{what}: rel-L2 {r:.4e} (<= {rel}), cos {c:.6f} (>= {cos})'
+    return r, c
+
+
+@pytest.fixture(scope='module')
+def small():
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    assert set(eng.expected_params()) == set(sd), 'engine and oracle disagree on the state_dict key set'
+    eng.load_state_dict(sd)
+    return eng, sd, ocfg, {k: torch.from_numpy(g[k]) for k in g.files if k != 'seed_weights'}
+
+
+def test_small_eps_vs_golden(small):
+    eng, sd, ocfg, g = small
+    eng.prepare(g['hint'], g['ctx'])
+    out = eng.eps(g['x'], g['t'])
+    check_eps(out, g['eps'], what='eps')
+    # same call again (plan re-use, no state leak)
+    out2 = eng.eps(g['x'], g['t'])
+    assert torch.equal(out, out2)
+
+
+def test_small_eps_control_variants(small):
+    eng, sd, ocfg, g = small
+    eng.prepare(g['hint'], g['ctx'], control_scales=[float(s) for s in g['scales']])
+    check_eps(eng.eps(g['x'], g['t']), g['eps_scaled'], what='control_scales')
+    eng.prepare(g['hint'], g['ctx'], only_mid_control=True)
+    check_eps(eng.eps(g['x'], g['t']), g['eps_mid'], what='only_mid_control')
+    eng.prepare(None, g['ctx'], latent_hw=(8, 8))
+    check_eps(eng.eps(g['x'], g['t']), g['eps_noctl'], what='c_concat None')
+
+
+def test_small_eps_vs_oracle_other_shape(small):
+    """non-square latent, batch 3, per-sample timesteps: oracle evaluated live."""
+    eng, sd, ocfg, _ = small
+    gen = torch.Generator().manual_seed(99)
+    B, h, w = 3, 4, 12
+    x = torch.randn(B, 4, h, w, generator=gen); hint = torch.rand(B, 6, 8 * h, 8 * w, generator=gen)
+    ctx = torch.randn(B, 77, ocfg.context_dim, generator=gen); t = torch.tensor([1, 500, 999])
+    ref = sampler.apply_model(sd, ocfg, x, t, {'c_crossattn': [ctx], 'c_concat': [hint]})
+    eng.prepare(hint, ctx)
+    check_eps(eng.eps(x, t), ref, what='eps 3x4x12')
+
+
+def test_per_sample_independence(small):
+    """B=2 must equal two B=1 evaluations (every op on the path is per-sample)."""
+    eng, sd, ocfg, g = small
+    eng.prepare(g['hint'], g['ctx'])
+    both = eng.eps(g['x'], g['t']).clone()
+    for i in range(2):
+        eng.prepare(g['hint'][i:i + 1], g['ctx'][i:i + 1])
+        one = eng.eps(g['x'][i:i + 1], g['t'][i:i + 1])
+        check_eps(one, both[i:i + 1], rel=5e-3, cos=0.9999, what=f'sample {i}')
+
+
+def test_small_sample_loop(small):
+    eng, sd, ocfg, g = small
+    sch = sampler.Schedule().make_ddim(5)
+    eng.prepare(g['hint'], g['ctx'])
+    out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    check_eps(out, g['x5'], rel=6e-2, cos=0.99, what='5-step latent')
+    # CFG 9: prepared with 2B, unconditional first (cddim.py:25-31), hint shared (diffusion_makeup.py:401)
+    eng.prepare(torch.cat([g['hint'], g['hint']]), torch.cat([g['uctx'], g['ctx']]))
+    out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                     cfg_scale=9.0)
+    check_eps(out, g['x5_cfg'], rel=0.15, cos=0.99, what='5-step CFG latent')
+
+
+def test_param_counts_full():
+    eng = MkdEngine(NetConfig())
+    assert abs(eng.param_count('unet') / 1e6 - 859.52) < 0.01
+    assert abs(eng.param_count('control') / 1e6 - 361.28) < 0.01
+    eng.close()
+
+
+def test_missing_weight_is_loud():
+    from makeupdiffuse_amd.lib import MkdError
+    eng = MkdEngine(NetConfig(**SMALL))
+    with pytest.raises(MkdError):
+        eng.finalize()
+    with pytest.raises(MkdError):
+        eng.prepare(torch.rand(1, 6, 64, 64), torch.randn(1, 77, 64))
+
+
+@pytest.mark.timeout(900)
+def test_full_size_eps_vs_oracle():
+    """BASELINE full architecture (859.5 M + 361.3 M params), B=1, 256x256: one eps eval vs the fp32 CPU oracle."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cfg = nets.FULL
+    sd = nets.init_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 32, 32, generator=gen); hint = torch.rand(1, 6, 256, 256, generator=gen)
+    ctx = torch.randn(1, 77, 768, generator=gen); t = torch.tensor([501])
+    ref = sampler.apply_model(sd, cfg, x, t, {'c_crossattn': [ctx], 'c_concat': [hint]})
+    eng = MkdEngine(NetConfig())
+    eng.load_state_dict(sd)
+    del sd
+    eng.prepare(hint, ctx)
+    r, c = check_eps(eng.eps(x, t), ref, what='full-size eps')
+    print(f'full-size eps: rel-L2 {r:.4e} cos {c:.6f} launches {eng.eps_launches()} GFLOP {eng.eps_flops() / 1e9:.1f}')
+    assert abs(eng.eps_flops() / 2e9 - 121.42) < 1.5     # 121.42 GMAC per sample per eval
+    eng.close()

@@ -1,0 +1,234 @@
+"""-m gpu: every HIP kernel through the C ABI vs a plain torch fp32 reference of the same op
+(inputs pre-rounded to bf16 so only accumulation order / output rounding differ)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, L, P, assert_close_bf16, bf, sync
+
+pytestmark = pytest.mark.gpu
+
+
+def gemm(A, W, bias=None, rowbias=None, rpb=1, R=None, scale=1.0, act=0, out_f32=False, conv=None, splitk=0,
+         ldc=None, lda=None):
+    lib = L()
+    N, K = W.shape
+    if conv is None:
+        M = A.shape[0]
+        lda_ = A.stride(0) if lda is None else lda
+        cv = (0, 0, 0, 0, 0, 0, 0, 1, 0)
+    else:
+        B, Hin, Win, Cin, Hout, Wout, stride, up = conv
+        M = B * Hout * Wout
+        lda_ = Cin if lda is None else lda
+        cv = (1, B, Hin, Win, Cin, Hout, Wout, stride, up)
+    ldc_ = N if ldc is None else ldc
+    out = torch.zeros((M, ldc_), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    rc = lib.mkd_gemm_bf16(P(A), lda_, P(W), K, P(bias), P(rowbias), 0 if rowbias is None else rowbias.stride(0), rpb,
+                           P(R), 0 if R is None else R.stride(0), float(scale), act, P(out), ldc_, int(out_f32), M, N, K,
+                           *cv, splitk, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    return out
+
+
+@pytest.mark.parametrize('M,N,K,splitk', [(200, 320, 320, 0), (128, 1280, 1280, 0), (128, 1280, 1280, 5), (8, 1280, 320, 0),
+                                          (77 * 2, 640, 768, 0), (1024, 64, 64, 1), (300, 192, 2560, 3), (4096, 320, 320, 1)])
+def test_gemm_linear(M, N, K, splitk):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g).to(DEV)
+    out = gemm(A, W, bias=bias, splitk=splitk)
+    ref = A.float() @ W.float().t() + bias
+    assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
+
+
+def test_gemm_epilogue_variants():
+    g = torch.Generator().manual_seed(7)
+    M, N, K, rpb = 512, 640, 640, 128
+    A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g).to(DEV)
+    rowbias = torch.randn(M // rpb, N + 64, generator=g).to(DEV)[:, 32:32 + N]   # strided view (ldrb > N)
+    R = bf(torch.randn(M, N, generator=g))
+    base = A.float() @ W.float().t() + bias
+    out = gemm(A, W, bias=bias, rowbias=rowbias, rpb=rpb)
+    assert_close_bf16(out, base + rowbias.repeat_interleave(rpb, 0), what='rowbias')
+    out = gemm(A, W, bias=bias, R=R, scale=0.5)
+    assert_close_bf16(out, base * 0.5 + R.float(), what='scale+residual')
+    out = gemm(A, W, bias=bias, act=1)
+    assert_close_bf16(out, F.silu(base), what='silu')
+    out = gemm(A, W, bias=bias, out_f32=True)
+    assert out.dtype == torch.float32
+    assert_close_bf16(out, base, rel=1e-5 * 50, what='f32 out')
+    # strided output (write into a channel slice of a wider buffer) must not touch the rest
+    out = gemm(A, W, bias=bias, ldc=N + 128)
+    assert_close_bf16(out[:, :N], base, what='ldc')
+    assert (out[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up,pad_ld,splitk', [
+    (2, 16, 16, 64, 128, 1, 0, 0, 0), (2, 16, 16, 64, 64, 2, 0, 0, 0), (1, 8, 8, 128, 128, 1, 1, 0, 0),
+    (2, 12, 20, 16, 32, 1, 0, 0, 1), (3, 8, 8, 320, 320, 1, 0, 64, 0), (2, 4, 4, 1280, 1280, 1, 0, 0, 0),
+    (2, 32, 32, 96, 256, 2, 0, 0, 0), (1, 4, 4, 2560, 1280, 1, 0, 0, 7)])
+def test_gemm_conv3x3(B, H, W_, Cin, Cout, stride, up, pad_ld, splitk):
+    lib = L()
+    g = torch.Generator().manual_seed(B * H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    ld = Cin + pad_ld
+    xn = torch.zeros(B, H, W_, ld, device=DEV, dtype=torch.bfloat16)
+    xn[..., :Cin] = xb.permute(0, 2, 3, 1)
+    if pad_ld:
+        xn[..., Cin:] = 99.0          # poison: must never be read
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    wf = wbf.float().contiguous()
+    assert lib.mkd_pack_conv_weight(P(wf), P(wp), Cout, Cin, 3, 3, None) == 0
+    xr = xb.float()
+    if up:
+        xr = F.interpolate(xr, scale_factor=2, mode='nearest')
+    ref = F.conv2d(xr, wbf.float(), bias, stride=stride, padding=1)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    out = gemm(xn, wp, bias=bias, conv=(B, H, W_, Cin, Hout, Wout, stride, up), lda=ld, splitk=splitk)
+    out = out.float().view(B, Hout, Wout, Cout).permute(0, 3, 1, 2)
+    assert_close_bf16(out, ref, what='conv3x3')
+
+
+@pytest.mark.parametrize('B,hw,C,silu,eps,pad', [(2, 64, 320, 1, 1e-5, 0), (3, 256, 640, 0, 1e-6, 0), (2, 16, 2560, 1, 1e-5, 0),
+                                                (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0),
+                                                (1, 64, 1920, 1, 1e-5, 0)])
+def test_groupnorm(B, hw, C, silu, eps, pad):
+    lib = L()
+    g = torch.Generator().manual_seed(C + hw)
+    x = bf(torch.randn(B, hw, C + pad, generator=g) * 2 + 0.5)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV); beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    y = torch.zeros(B, hw, C, device=DEV, dtype=torch.bfloat16)
+    rc = lib.mkd_groupnorm(P(x), C + pad, P(gamma), P(beta), eps, silu, P(y), C, B, hw, C, 32, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    xr = x[..., :C].float().permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert_close_bf16(y.float().permute(0, 2, 1), ref, what='groupnorm')
+
+
+@pytest.mark.parametrize('rows,d', [(100, 320), (37, 640), (16, 1280), (5, 64)])
+def test_layernorm(rows, d):
+    lib = L()
+    g = torch.Generator().manual_seed(d)
+    x = bf(torch.randn(rows, d, generator=g) * 3 + 1)
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV); beta = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    y = torch.empty_like(x)
+    assert lib.mkd_layernorm(P(x), P(gamma), P(beta), 1e-5, P(y), rows, d, None) == 0, lib.mkd_last_error()
+    sync()
+    assert_close_bf16(y, F.layer_norm(x.float(), (d,), gamma, beta, 1e-5), what='layernorm')
+
+
+@pytest.mark.parametrize('B,Tq,Tk,heads,dh', [(2, 256, 256, 8, 40), (1, 1024, 1024, 2, 40), (2, 64, 64, 8, 160), (2, 16, 16, 8, 160),
+                                            (2, 256, 77, 8, 80), (2, 100, 77, 4, 40), (1, 64, 77, 2, 32), (2, 16, 77, 8, 160),
+                                            (1, 200, 130, 3, 64)])
+def test_attention(B, Tq, Tk, heads, dh):
+    lib = L()
+    g = torch.Generator().manual_seed(Tq + Tk + dh)
+    d = heads * dh
+    q = bf(torch.randn(B * Tq, d, generator=g)); kv = bf(torch.randn(B * Tk, 2 * d, generator=g))
+    o = torch.zeros(B * Tq, d, device=DEV, dtype=torch.bfloat16)
+    scale = dh ** -0.5
+    k = kv[:, :d]; v = kv[:, d:]
+    rc = lib.mkd_attention(P(q), d, P(k), 2 * d, C.c_void_p(kv.data_ptr() + 2 * d), 2 * d, P(o), d, B, Tq, Tk, heads, dh, scale, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    qf = q.float().view(B, Tq, heads, dh).transpose(1, 2)
+    kf = k.float().reshape(B, Tk, heads, dh).transpose(1, 2)
+    vf = v.float().reshape(B, Tk, heads, dh).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).transpose(1, 2).reshape(B * Tq, d)
+    # P is rounded to bf16 before the PV product: allow 2x the generic kernel budget
+    assert_close_bf16(o, ref, rel=8e-3, what='attention')
+
+
+def test_attention_spiked_scores():
+    """online-softmax rescale path: one key far above the rest, placed in a late tile."""
+    lib = L()
+    B, Tq, Tk, heads, dh = 1, 64, 256, 1, 40
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(Tq, dh, generator=g); k = torch.randn(Tk, dh, generator=g); v = torch.randn(Tk, dh, generator=g)
+    k[200] = q[5] * 4.0
+    q, k, v = bf(q), bf(k), bf(v)
+    o = torch.zeros(Tq, dh, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_attention(P(q), dh, P(k), dh, P(v), dh, P(o), dh, B, Tq, Tk, heads, dh, dh ** -0.5, None) == 0
+    sync()
+    ref = torch.softmax(q.float() @ k.float().t() * dh ** -0.5, -1) @ v.float()
+    assert_close_bf16(o, ref, rel=8e-3, what='attention spike')
+
+
+def test_geglu():
+    lib = L()
+    g = torch.Generator().manual_seed(1)
+    rows, inner = 77, 1280
+    x = bf(torch.randn(rows, 2 * inner, generator=g) * 2)
+    y = torch.empty(rows, inner, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_geglu(P(x), P(y), rows, inner, None) == 0
+    sync()
+    a, gate = x.float().chunk(2, -1)
+    assert_close_bf16(y, a * F.gelu(gate), what='geglu')
+
+
+@pytest.mark.parametrize('Cin,Cout,stride,in_nchw,out_nchw,act', [(4, 320, 1, 1, 0, 0), (6, 16, 1, 1, 0, 1), (320, 4, 1, 0, 1, 0), (16, 32, 2, 0, 0, 1)])
+def test_conv3x3_direct(Cin, Cout, stride, in_nchw, out_nchw, act):
+    lib = L()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B, H, W_ = 2, 16, 24
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(w.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    if in_nchw:
+        xin = x.to(DEV).contiguous(); xr = xin
+    else:
+        xb = bf(x); xin = xb.permute(0, 2, 3, 1).contiguous(); xr = xb.float()
+    ref = F.conv2d(xr, w.float(), bias, stride=stride, padding=1)
+    if act:
+        ref = F.silu(ref)
+    Ho, Wo = ref.shape[2:]
+    add = bf(torch.randn(B, Ho, Wo, Cout, generator=g)) if not out_nchw else None
+    if add is not None:
+        ref = ref + add.float().permute(0, 3, 1, 2)
+    out = torch.zeros((B, Cout, Ho, Wo) if out_nchw else (B, Ho, Wo, Cout), device=DEV,
+                      dtype=torch.float32 if out_nchw else torch.bfloat16)
+    rc = lib.mkd_conv3x3_direct(P(xin), in_nchw, P(wp), P(bias), P(out), out_nchw, act, P(add), B, H, W_, Cin, Cout, stride, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    o = out if out_nchw else out.float().permute(0, 3, 1, 2)
+    assert_close_bf16(o, ref, what='conv3x3_direct')
+
+
+def test_ddim_step_matches_reference_formula():
+    """cddim.py:39-40, 56-78 in fp32: bit-for-bit is not required (fma contraction), 1e-6 relative is."""
+    lib = L()
+    g = torch.Generator().manual_seed(0)
+    n = 2 * 4 * 32 * 32
+    x = torch.randn(n, generator=g).to(DEV); ec = torch.randn(n, generator=g).to(DEV); eu = torch.randn(n, generator=g).to(DEV)
+    noise = torch.randn(n, generator=g).to(DEV)
+    a_t, a_prev, sigma, s = 0.0057755, 0.00728173, 0.05, 9.0
+    s1m = math.sqrt(1 - a_t)
+    xp = torch.empty_like(x); x0 = torch.empty_like(x)
+    rc = lib.mkd_ddim_step(P(x), P(ec), P(eu), s, a_t, a_prev, sigma, s1m, P(noise), 1.0, P(xp), P(x0), n, None)
+    assert rc == 0
+    sync()
+    e = eu + s * (ec - eu)
+    r0 = (x - s1m * e) / math.sqrt(a_t)
+    rp = math.sqrt(a_prev) * r0 + math.sqrt(1 - a_prev - sigma ** 2) * e + sigma * noise
+    assert torch.allclose(x0, r0, rtol=2e-6, atol=1e-5)
+    assert torch.allclose(xp, rp, rtol=2e-6, atol=1e-5)
+    # no CFG, no noise, no x0
+    rc = lib.mkd_ddim_step(P(x), P(ec), None, 1.0, a_t, a_prev, 0.0, s1m, None, 1.0, P(xp), None, n, None)
+    assert rc == 0
+    sync()
+    r0 = (x - s1m * ec) / math.sqrt(a_t)
+    assert torch.allclose(xp, math.sqrt(a_prev) * r0 + math.sqrt(1 - a_prev) * ec, rtol=2e-6, atol=1e-5)
