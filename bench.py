@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py — makeup-transfer images/sec at 256x256, 50 DDIM steps (BASELINE.json metric), MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg] [--res 256|512] [--batch 8]
+
+One "step" = one pass of the hot path over one batch: mkd_prepare (hint embedding + cross-attn K/V caches)
++ the full 50-step DDIM reverse loop x_T -> latent (ControlNet + UNet every step), inputs resident in HBM.
+N > 1: launched by torch.distributed.run, one rank per GPU, batch-sharded replicas (weak scaling, B per GPU
+fixed), a single RCCL all-gather of the finished latents per step.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from makeupdiffuse_amd import dist as mdist  # noqa: E402
+from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
+from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+MFMA_KINDS = ('gemm_conv3x3_tn128', 'gemm_conv3x3_tn64', 'gemm_linear_tn128', 'gemm_linear_tn64', 'attention')
+
+
+def synth_inputs(lo, hi, res, ctx_dim, device):
+    """SURVEY.md §8d synthetic inputs, generated PER SAMPLE so shards do not depend on the world size."""
+    h = res // 8
+    xs, hints, ctxs, uctxs = [], [], [], []
+    for i in range(lo, hi):
+        g = torch.Generator().manual_seed(1234 + i)
+        xs.append(torch.randn(1, 4, h, h, generator=g))
+        g = torch.Generator().manual_seed(5678 + i)
+        hints.append(torch.rand(1, 6, res, res, generator=g))
+        g = torch.Generator().manual_seed(91011 + i)
+        ctxs.append(torch.randn(1, 77, ctx_dim, generator=g))
+        uctxs.append(torch.randn(1, 77, ctx_dim, generator=g))
+    cat = lambda v: torch.cat(v).to(device)
+    return cat(xs), cat(hints), cat(ctxs), cat(uctxs)
+
+
+def gen_weights(eng, seed, keep_cpu):
+    """Seeded N(0,1/fan_in) weights generated on the device, optionally mirrored to the host
+    for the CPU baseline so both legs use the same numbers."""
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(seed)
+    cpu = {} if keep_cpu else None
+    for name, shape in eng.expected_params().items():
+        is_norm = ('.norm' in name or 'in_layers.0' in name or 'out_layers.0' in name
+                   or name.endswith('out.0.weight') or name.endswith('out.0.bias'))
+        if len(shape) == 1:
+            if is_norm:
+                t = (torch.ones if name.endswith('weight') else torch.zeros)(shape, device=eng.device)
+            else:
+                t = 0.02 * torch.randn(shape, generator=g, device=eng.device)
+        else:
+            t = torch.randn(shape, generator=g, device=eng.device) / float(np.prod(shape[1:])) ** 0.5
+        eng.load_weight(name, t)
+        if keep_cpu:
+            cpu[name] = t.cpu()
+    eng.finalize()
+    return cpu
+
+
+def cpu_baseline(sd_cpu, res, x1, hint1, ctx1, gpu_eps1, n_evals, ddim_steps):
+    """The reference's CPU path cannot run here (ldm/cldm absent), so this times the fp32 torch RESTATEMENT
+    (oracle/, kind "port") on the host cores: BASELINE config 1 (B=1, fp32) bounded to n_evals eps evaluations."""
+    from oracle import nets, sampler
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = nets.FULL
+    cond = {'c_crossattn': [ctx1], 'c_concat': [hint1]}
+    t = torch.tensor([981])
+    times, ref = [], None
+    for _ in range(n_evals):
+        t0 = time.perf_counter()
+        ref = sampler.apply_model(sd_cpu, cfg, x1, t, cond)
+        times.append(time.perf_counter() - t0)
+    s_eval = float(np.median(times))
+    rel = float(((gpu_eps1.cpu() - ref).norm() / ref.norm()).item())
+    cos = float(torch.nn.functional.cosine_similarity(gpu_eps1.cpu().flatten(), ref.flatten(), dim=0).item())
+    return {'value': 1.0 / (s_eval * ddim_steps), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_evals} eps evaluations of B=1 {res}x{res} fp32 (oracle/ restatement, same weights); '
+                      f's/eval={s_eval:.3f}, x{ddim_steps} steps per image',
+            's_per_eval': s_eval, 'gpu_vs_cpu_eps_rel_l2': rel, 'gpu_vs_cpu_eps_cos': cos}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--ddim-steps', type=int, default=50)
+    ap.add_argument('--cfg', action='store_true', help='classifier-free guidance 9.0 (2 evals / step)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-evals', type=int, default=3)
+    ap.add_argument('--graph', type=int, default=0)
+    args = ap.parse_args()
+
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU path for the product)')
+    torch.cuda.set_device(local)
+    dev = torch.device(f'cuda:{local}')
+
+    cfg = NetConfig()
+    eng = MkdEngine(cfg, dev)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    sd_cpu = gen_weights(eng, seed=0, keep_cpu=want_cpu)
+
+    B = args.batch
+    n_total = B * world
+    lo, hi = mdist.shard_range(n_total, rank, world)
+    x_T, hint, ctx, uctx = synth_inputs(lo, hi, args.res, cfg.context_dim, dev)
+    sch = DDIMSchedule().make_ddim(args.ddim_steps)
+    cfg_scale = 9.0 if args.cfg else 1.0
+
+    def one_step():
+        if args.cfg:       # uncond first (cddim.py:25-31), same hint (diffusion_makeup.py:401)
+            eng.prepare(torch.cat([hint, hint]), torch.cat([uctx, ctx]))
+        else:
+            eng.prepare(hint, ctx)
+        lat = eng.sample(x_T, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                         cfg_scale=cfg_scale, use_graph=bool(args.graph))
+        return mdist.gather_shards(lat, n_total)
+
+    for _ in range(args.warmup):
+        out = one_step()
+    mdist.barrier(); torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = one_step()
+    ev1.record()
+    mdist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = mdist.max_over_ranks(dt, dev)
+    assert torch.isfinite(out).all(), 'non-finite latents'
+
+    if rank == 0:
+        evals_per_step = args.ddim_steps
+        eps_flops = eng.eps_flops()                      # executed FLOPs of one eval at the prepared batch
+        loop_ms = ev0.elapsed_time(ev1) / args.steps
+        # per-kernel-class device time of ONE eps evaluation, HIP events around every launch on the same stream
+        tt = torch.full((eng.batch,), int(sch.ddim_timesteps[-1]), dtype=torch.int64, device=dev)
+        x_in = torch.cat([x_T, x_T]) if args.cfg else x_T
+        eng.eps_profile(x_in, tt)
+        prof = eng.eps_profile(x_in, tt)
+        tot_ms = sum(v['ms'] for v in prof.values())
+        dom = max((k for k in prof if k in MFMA_KINDS), key=lambda k: prof[k]['ms'])
+        d = prof[dom]
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                    'launches_per_eval': d['launches'], 'avg_launch_us': 1e3 * d['ms'] / max(1, d['launches']),
+                    'flops_per_launch': d['flops'] / max(1, d['launches']),
+                    'share_of_eval_time': d['ms'] / tot_ms if tot_ms else None}
+        loop_tflops = eps_flops * evals_per_step / (loop_ms * 1e-3) / 1e12
+        result = {
+            'metric': 'makeup-transfer images/sec @256x256, 50 DDIM steps' if args.res == 256 and args.ddim_steps == 50
+                      else f'makeup-transfer images/sec @{args.res}x{args.res}, {args.ddim_steps} DDIM steps',
+            'value': n_total * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'batch={B}/GPU {args.res}x{args.res}, {args.ddim_steps} DDIM steps, eta 0, '
+                                   + ('CFG 9.0 (2 evals/step)' if args.cfg else 'no CFG (1 eval/step)')
+                                   + ', ControlNet+UNet every step, random-init SD-1.5 ControlNet weights, latents out',
+                       'global_batch': n_total, 'parallelism': f'batch-shard x{world}, 1 all-gather/step'},
+            'roofline': roofline,
+            'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
+                     'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
+                     'launches_per_eval': eng.eps_launches(), 'device_gb': eng.device_bytes() / 1e9},
+            'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items()},
+        }
+        if want_cpu:
+            eng.prepare(hint[:1], ctx[:1])
+            g1 = eng.eps(x_T[:1], torch.tensor([981], device=dev))
+            result['cpu_baseline'] = cpu_baseline(sd_cpu, args.res, x_T[:1].cpu(), hint[:1].cpu(), ctx[:1].cpu(), g1,
+                                                  args.cpu_evals, args.ddim_steps)
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    mdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -66,6 +66,11 @@ struct Epi {
 
 typedef std::function<int(hipStream_t)> OpFn;
 
+enum OpKind { K_GEMM_CONV128 = 0, K_GEMM_CONV64, K_GEMM_LIN128, K_GEMM_LIN64, K_GROUPNORM, K_LAYERNORM, K_ATTENTION,
+              K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_tn128", "gemm_conv3x3_tn64", "gemm_linear_tn128", "gemm_linear_tn64",
+                                         "groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
+
 }  // namespace
 
 struct mkd_ctx {
@@ -98,6 +103,7 @@ struct mkd_ctx {
     float* gn_ws = nullptr; size_t gn_ws_bytes = 0, gn_need = 0;
     std::vector<OpFn> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
+    std::vector<int> kind_eps; std::vector<double> opflops_eps; std::vector<int> oplaunch_eps;
     bool dry = false; bool counting_eps = false;
     std::map<std::string, Tensor> kv_cache;       // transformer prefix -> [B*77, 2d]
     Tensor hint_emb;
@@ -369,9 +375,12 @@ struct mkd_ctx {
     }
 
     // ---- plan building ------------------------------------------------------------------------------
-    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops) {
+    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops, int kind = K_MISC) {
         if (counting_eps) { launches_eps += launches; flops_eps += flops; }
-        if (!dry) plan.push_back(std::move(f));
+        if (!dry) {
+            plan.push_back(std::move(f));
+            if (counting_eps) { kind_eps.push_back(kind); opflops_eps.push_back(flops); oplaunch_eps.push_back(launches); }
+        }
     }
     std::vector<OpFn>* cur_plan = nullptr;
 
@@ -389,7 +398,8 @@ struct mkd_ctx {
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
         push(*cur_plan, [self, a](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws; return launch_gemm(b, st); },
-             s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K);
+             s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
+             a.conv ? (a.N % 128 == 0 ? K_GEMM_CONV128 : K_GEMM_CONV64) : (a.N % 128 == 0 ? K_GEMM_LIN128 : K_GEMM_LIN64));
     }
     void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
         GemmArgs a; memset(&a, 0, sizeof(a));
@@ -416,19 +426,19 @@ struct mkd_ctx {
         Tensor t = in;
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out](hipStream_t st) {
             return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws, st);
-        }, 2, 0.0);
+        }, 2, 0.0, K_GROUPNORM);
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
-        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0);
+        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0, K_LAYERNORM);
     }
     void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
                  int B_, int Tq, int Tk, int heads, int dh) {
         const float scale = 1.0f / sqrtf((float)dh);
         push(*cur_plan, [=](hipStream_t st) { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B_, Tq, Tk, heads, dh, scale, st); },
-             1, 4.0 * B_ * heads * (double)Tq * Tk * dh);
+             1, 4.0 * B_ * heads * (double)Tq * Tk * dh, K_ATTENTION);
     }
     void op_geglu(const bf16_t* x, bf16_t* y, int rows, int inner) {
-        push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0);
+        push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0, K_GEGLU);
     }
     void op_copy(const bf16_t* src, int ld_src, bf16_t* dst, int ld_dst, int rows, int cols) {
         push(*cur_plan, [=](hipStream_t st) { return launch_copy_strided(src, ld_src, dst, ld_dst, rows, cols, st); }, 1, 0.0);
@@ -539,7 +549,7 @@ struct mkd_ctx {
                 const int Bn = B, hh = h, ww = w, cin = b.cin, cout = b.cout;
                 push(*cur_plan, [self, wgt, bias, o, add, Bn, hh, ww, cin, cout](hipStream_t st) {
                     return launch_conv3x3_direct(self->io_x, 1, wgt, bias, o.p, 0, 0, add, Bn, hh, ww, cin, cout, 1, st);
-                }, 1, 2.0 * B * h * w * b.cout * 9 * b.cin);
+                }, 1, 2.0 * B * h * w * b.cout * 9 * b.cin, K_CONV_DIRECT);
                 hcur = o;
             } else if (b.kind == 1) {
                 Tensor o = talloc(persist, hcur.B, hcur.H, hcur.W, b.cout);
@@ -628,7 +638,7 @@ struct mkd_ctx {
     void build_eps_plan() {
         cur_plan = &plan_eps;
         counting_eps = true;
-        flops_eps = 0; launches_eps = 0;
+        flops_eps = 0; launches_eps = 0; kind_eps.clear(); opflops_eps.clear(); oplaunch_eps.clear();
         mkd_ctx* self = this;
         std::vector<Tensor> cn_feats, hs;
         Tensor cn_mid, u_mid;
@@ -715,7 +725,7 @@ struct mkd_ctx {
             const int Bn = B, hh = h, ww = w, cin = cat.C, cout = cfg.out_channels;
             push(*cur_plan, [self, g, wgt, bias, Bn, hh, ww, cin, cout](hipStream_t st) {
                 return launch_conv3x3_direct(g.p, 0, wgt, bias, self->io_out, 1, 0, nullptr, Bn, hh, ww, cin, cout, 1, st);
-            }, 1, 2.0 * B * h * w * cfg.out_channels * 9 * cat.C);
+            }, 1, 2.0 * B * h * w * cfg.out_channels * 9 * cat.C, K_CONV_DIRECT);
             temp.release(mk);
         }
         counting_eps = false;
@@ -779,6 +789,30 @@ struct mkd_ctx {
         io_x = x; io_t = t; io_out = out;
         for (auto& f : plan_eps) { int rc = f(stream); if (rc) return rc; }
         return 0;
+    }
+
+    // one eps with a hipEvent pair around every plan op: per-kernel-class device time (bench roofline)
+    int eps_profile(const float* x, const int64_t* t, float* out, hipStream_t stream, double* ms, double* flops, int* launches) {
+        if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps_profile before mkd_prepare");
+        io_x = x; io_t = t; io_out = out;
+        const size_t n = plan_eps.size();
+        std::vector<hipEvent_t> ev(n + 1);
+        for (auto& e : ev) MKD_HIP_CHECK(hipEventCreate(&e));
+        int rc = 0;
+        MKD_HIP_CHECK(hipEventRecord(ev[0], stream));
+        for (size_t i = 0; i < n && !rc; ++i) {
+            rc = plan_eps[i](stream);
+            if (!rc && hipEventRecord(ev[i + 1], stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipEventRecord");
+        }
+        if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipStreamSynchronize");
+        for (int k = 0; k < K_COUNT; ++k) { ms[k] = 0; flops[k] = 0; launches[k] = 0; }
+        for (size_t i = 0; i < n && !rc; ++i) {
+            float dt = 0.f;
+            if (hipEventElapsedTime(&dt, ev[i], ev[i + 1]) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime"); break; }
+            ms[kind_eps[i]] += dt; flops[kind_eps[i]] += opflops_eps[i]; launches[kind_eps[i]] += oplaunch_eps[i];
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+        return rc;
     }
 
     int sample(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
@@ -910,6 +944,13 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
     if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
     return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
                        (hipStream_t)stream);
+}
+int mkd_kind_count(void) { return K_COUNT; }
+const char* mkd_kind_name(int kind) { return (kind >= 0 && kind < K_COUNT) ? kKindNames[kind] : nullptr; }
+int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream, double* ms_per_kind,
+                    double* flops_per_kind, int* launches_per_kind) {
+    if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile: null argument");
+    return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind);
 }
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }

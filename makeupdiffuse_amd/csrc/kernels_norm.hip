@@ -20,9 +20,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // threads = V * P where V = C/8 vectors per pixel (thread's vector id = tid % V, fixed).
+// Deterministic: per-thread register sums -> LDS -> one thread per group adds them in a fixed order.
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, int ld, int hw, int C, int groups,
                                 int rows_per_chunk, float* __restrict__ partials) {
-    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    extern __shared__ __attribute__((aligned(16))) float s_part[];   // [2][T][8]
     const int V = C >> 3;
     const int T = blockDim.x;
     const int P = T / V;
@@ -32,8 +33,6 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, int ld, int hw, in
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(hw, r0 + rows_per_chunk);
-    if (tid < groups) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-    __syncthreads();
     float sum[8], sq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
@@ -46,17 +45,21 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, int ld, int hw, in
             sum[j] += f; sq[j] += f * f;
         }
     }
-    const int cg = C / groups;
+    float* ssum = s_part;
+    float* ssq = s_part + T * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int g = (v * 8 + j) / cg;
-        atomicAdd(&s_sum[g], sum[j]);
-        atomicAdd(&s_sq[g], sq[j]);
-    }
+    for (int j = 0; j < 8; ++j) { ssum[tid * 8 + j] = sum[j]; ssq[tid * 8 + j] = sq[j]; }
     __syncthreads();
     if (tid < groups) {
+        const int cg = C / groups;
+        float a = 0.f, q = 0.f;
+        for (int p = 0; p < P; ++p)
+            for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+                const int idx = (p * V + (c >> 3)) * 8 + (c & 7);
+                a += ssum[idx]; q += ssq[idx];
+            }
         float* o = partials + ((size_t)(b * gridDim.x + chunk) * groups + tid) * 2;
-        o[0] = s_sum[tid]; o[1] = s_sq[tid];
+        o[0] = a; o[1] = q;
     }
 }
 
@@ -189,7 +192,7 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
     const int nchunks = gn_chunks(hw);
     const int rows_per_chunk = (hw + nchunks - 1) / nchunks;
     dim3 grid(nchunks, batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 0, stream, x, ld_in, hw, C, groups, rows_per_chunk, partials);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)threads * 16 * sizeof(float), stream, x, ld_in, hw, C, groups, rows_per_chunk, partials);
     MKD_LAUNCH_CHECK("gn_stats_kernel");
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
                        hw, C, groups, rows_per_chunk, nchunks, partials);

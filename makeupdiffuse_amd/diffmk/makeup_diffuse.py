@@ -1,0 +1,283 @@
+"""``diffmk.makeup_diffuse`` — inference-side drop-in for the reference model classes on the hot path.
+
+Mirrors, for the DDIM sampling path only:
+  * ``apply_model``                 reference diffmk/makeup_diffuse.py:152-170
+  * ``get_input`` cond assembly     reference diffmk/makeup_diffuse.py:42-57, diffmk/makeup_controlnet.py:137-167
+  * ``sample_log`` / ``log_results``reference diffmk/diffusion_makeup.py:360-411 (UPSTREAM ControlLDM.sample_log)
+Training losses, teachers, PL hooks and the VAE/CLIP stages are out of scope for this path;
+calling them raises NotImplementedError rather than returning something different from the reference.
+The arithmetic runs in libmkd (HIP); there is no CPU implementation behind these classes."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ..ddim import DDIMSampler
+from ..engine import MkdEngine, NetConfig
+from ..lib import MkdError
+from ..schedule import DDIMSchedule
+
+
+def _key(t: Optional[torch.Tensor]):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+class BaseMakeUpDiffuse:
+    """ControlLDM-shaped inference model: ControlNet(hint = src ‖ ref) -> 13 residuals -> ControlledUnet."""
+
+    def __init__(self, control_stage_config: dict, unet_config: dict, first_stage_config: Optional[dict] = None,
+                 cond_stage_config: Optional[dict] = None, linear_start: float = 0.00085, linear_end: float = 0.0120,
+                 timesteps: int = 1000, beta_schedule: str = 'linear', scale_factor: float = 0.18215,
+                 only_mid_control: bool = False, parameterization: str = 'eps', channels: int = 4, image_size: int = 64,
+                 conditioning_key: str = 'crossattn', first_stage_key: str = 'jpg', cond_stage_key: str = 'txt',
+                 control_key: str = 'ref_img', src_key: str = 'src_img', src_img_key: str = 'src_img',
+                 ref_img_key: str = 'ref_img', use_ema: bool = False, **unused_training_params):
+        if parameterization != 'eps':
+            raise NotImplementedError("parameterization must be 'eps' (base_diffusion_makeup.yaml:50)")
+        self.net_config = NetConfig.from_yaml_params(dict(control_stage_config.get('params', control_stage_config)),
+                                                     dict(unet_config.get('params', unet_config)))
+        self.first_stage_config, self.cond_stage_config = first_stage_config, cond_stage_config
+        self.extra_params = dict(unused_training_params)      # w_idt_src, lambda_lip, teacher_type, ... (training only)
+        self.parameterization = parameterization
+        self.only_mid_control = bool(only_mid_control)
+        self.control_scales: List[float] = [1.0] * self.net_config.n_control
+        self.scale_factor, self.channels, self.image_size = scale_factor, channels, image_size
+        self.conditioning_key = conditioning_key
+        self.first_stage_key, self.cond_stage_key, self.control_key = first_stage_key, cond_stage_key, control_key
+        self.src_img_key = src_img_key if src_img_key else src_key
+        self.ref_img_key = ref_img_key if ref_img_key else control_key
+        sch = DDIMSchedule(timesteps, linear_start, linear_end, beta_schedule)
+        self.schedule = sch
+        self.num_timesteps = sch.num_timesteps
+        for n in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
+                  'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod'):
+            setattr(self, n, getattr(sch, n))
+        self.device = torch.device('cpu')
+        self.engine: Optional[MkdEngine] = None
+        self._pending_sd: Optional[Dict[str, torch.Tensor]] = None
+        self._bound = None
+        self._cfg_cache = None
+        self.cond_stage_model = None          # callable(list[str]) -> [B,77,768]; CLIP is a "next" row
+        self.first_stage_model = None         # VAE decoder, "next" row
+        self.training = False
+
+    # ---- nn.Module-ish surface used by runs/test.py --------------------------------------------------------
+    def cpu(self):
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device('cuda', torch.cuda.current_device() if device is None else device))
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == 'cuda':
+            if self.engine is None:
+                self.engine = MkdEngine(self.net_config, device)
+                if self._pending_sd is not None:
+                    self.engine.load_state_dict(self._pending_sd, strict=True)
+                    self._pending_sd = None
+            for n in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod',
+                      'sqrt_one_minus_alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod'):
+                setattr(self, n, getattr(self, n).to(device))
+            self.device = device
+        return self
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """Accepts an upstream-named checkpoint dict (runs/test.py:59-60).  Keys outside the two nets
+        (first_stage_model.*, cond_stage_model.*, teacher_model*) are reported back as unexpected."""
+        sd = state_dict.get('state_dict', state_dict)
+        if self.engine is not None:
+            unused = self.engine.load_state_dict(sd, strict=strict)
+        else:
+            self._pending_sd = {k: v for k, v in sd.items()
+                                if k.startswith(MkdEngine.UNET_PREFIX) or k.startswith(MkdEngine.CONTROL_PREFIX)}
+            unused = [k for k in sd if k not in self._pending_sd]
+        return [], unused
+
+    def _require_engine(self) -> MkdEngine:
+        if self.engine is None:
+            raise MkdError('model is not on a HIP device: call .cuda() first (the hot path has no CPU implementation)')
+        return self.engine
+
+    # ---- conditioning -------------------------------------------------------------------------------------
+    def get_origin_img_input(self, batch: dict, k: str, bs: Optional[int] = None) -> torch.Tensor:
+        x = batch[k]
+        if bs is not None:
+            x = x[:bs]
+        return x.to(self.device).to(memory_format=torch.contiguous_format).float()
+
+    def get_learned_conditioning(self, txt: Sequence[str]) -> torch.Tensor:
+        if self.cond_stage_model is None:
+            raise NotImplementedError('CLIP text encoder (cond_stage_config) is not built yet (SURVEY.md §8f rank 3): '
+                                      "put a precomputed [B,77,768] embedding under batch['txt_emb'] or set cond_stage_model")
+        return self.cond_stage_model(list(txt)).to(self.device).float()
+
+    def get_cond_txt_coding(self, batch: dict, bs: Optional[int] = None) -> torch.Tensor:
+        if 'txt_emb' in batch:
+            c = batch['txt_emb']
+            return (c if bs is None else c[:bs]).to(self.device).float()
+        txt = batch[self.cond_stage_key]
+        return self.get_learned_conditioning(txt if bs is None else txt[:bs])
+
+    def get_unconditional_conditioning(self, N: int) -> torch.Tensor:
+        if getattr(self, 'uncond_embedding', None) is not None:
+            u = self.uncond_embedding.to(self.device).float()
+            return u.expand(N, -1, -1).contiguous() if u.shape[0] == 1 else u[:N]
+        return self.get_learned_conditioning([''] * N)
+
+    @torch.no_grad()
+    def get_input(self, batch: dict, k, bs: Optional[int] = None, *args, **kwargs):
+        """-> (None, c) with c_concat = [cat(src_img, ref_img, 1)] (source first) and c_crossattn = [text]."""
+        src = self.get_origin_img_input(batch, self.src_img_key, bs)
+        ref = self.get_origin_img_input(batch, self.ref_img_key, bs)
+        c = {'c_crossattn': [self.get_cond_txt_coding(batch, bs)], 'src_img': src, 'ref_img': ref,
+             'c_concat': [torch.cat((src, ref), 1)]}
+        return None, c
+
+    def _bind(self, hint: Optional[torch.Tensor], ctx: torch.Tensor, latent_hw) -> MkdEngine:
+        eng = self._require_engine()
+        key = (_key(hint), _key(ctx), tuple(latent_hw), tuple(self.control_scales), self.only_mid_control)
+        if key != self._bound:
+            eng.prepare(hint, ctx, latent_hw=tuple(latent_hw), control_scales=self.control_scales,
+                        only_mid_control=self.only_mid_control)
+            self._bound = key
+        return eng
+
+    def cfg_conditioning(self, uncond: dict, cond: dict) -> dict:
+        """[uncond; cond] batching (cddim.py:18-38), cached per (uncond, cond) pair so that a step-by-step
+        caller does not rebuild — and libmkd does not re-prepare — identical conditioning every step."""
+        def flat(c):
+            out = []
+            for k in sorted(c):
+                v = c[k]
+                if isinstance(v, list):
+                    out += [_key(t) for t in v]
+                elif isinstance(v, torch.Tensor):
+                    out.append(_key(v))
+            return tuple(out)
+        key = (flat(uncond), flat(cond))
+        if self._cfg_cache is None or self._cfg_cache[0] != key:
+            merged = {}
+            for k in cond:
+                if isinstance(cond[k], list):
+                    merged[k] = [torch.cat([uncond[k][i], cond[k][i]]) for i in range(len(cond[k]))]
+                elif isinstance(cond[k], torch.Tensor):
+                    merged[k] = torch.cat([uncond[k], cond[k]])
+                else:
+                    merged[k] = cond[k]
+            self._cfg_cache = (key, merged)
+        return self._cfg_cache[1]
+
+    # ---- the eps model ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def apply_model(self, x_noisy: torch.Tensor, t: torch.Tensor, cond: dict, return_all: bool = False, *args, **kwargs):
+        assert isinstance(cond, dict)
+        cond_txt = torch.cat(cond['c_crossattn'], 1) if len(cond['c_crossattn']) > 1 else cond['c_crossattn'][0]
+        hint = None
+        if cond.get('c_concat') is not None:
+            hint = torch.cat(cond['c_concat'], 1) if len(cond['c_concat']) > 1 else cond['c_concat'][0]
+        eng = self._bind(hint, cond_txt, x_noisy.shape[2:])
+        eps = eng.eps(x_noisy, t)
+        if not return_all:
+            return eps
+        return eps, self.predict_start_from_noise(x_t=x_noisy, t=t, noise=eps)
+
+    def predict_start_from_noise(self, x_t: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        a = self.sqrt_recip_alphas_cumprod.to(x_t.device)[t].view(-1, 1, 1, 1)
+        b = self.sqrt_recipm1_alphas_cumprod.to(x_t.device)[t].view(-1, 1, 1, 1)
+        return a * x_t - b * noise
+
+    # hooks the samplers use to stay on the device ----------------------------------------------------------------
+    def ddim_step(self, x, e_c, e_u, scale, a_t, a_prev, sigma_t, s1m_t, noise, temperature):
+        return self._require_engine().ddim_step(x, e_c, e_u, scale, a_t, a_prev, sigma_t, s1m_t, noise, temperature)
+
+    def sample_loop_fast(self, x_latent, cond, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas,
+                         unconditional_guidance_scale=1.0, unconditional_conditioning=None):
+        cfg_on = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
+        c = self.cfg_conditioning(unconditional_conditioning, cond) if cfg_on else cond
+        cond_txt = torch.cat(c['c_crossattn'], 1) if len(c['c_crossattn']) > 1 else c['c_crossattn'][0]
+        hint = None
+        if c.get('c_concat') is not None:
+            hint = torch.cat(c['c_concat'], 1) if len(c['c_concat']) > 1 else c['c_concat'][0]
+        eng = self._bind(hint, cond_txt, x_latent.shape[2:])
+        return eng.sample(x_latent, [int(v) for v in timesteps], [float(v) for v in alphas], [float(v) for v in alphas_prev],
+                          [float(v) for v in sqrt_one_minus_alphas],
+                          cfg_scale=float(unconditional_guidance_scale) if cfg_on else 1.0)
+
+    # ---- sampling drivers ----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_log(self, cond: dict, batch_size: int, ddim: bool, ddim_steps: int, **kwargs):
+        """UPSTREAM ControlLDM.sample_log: latent shape from the hint, x_T ~ N(0, I) unless given."""
+        if not ddim:
+            raise NotImplementedError('only the DDIM sampler is on the MakeupDiffuse test path')
+        sampler = DDIMSampler(self)
+        _, _, h, w = cond['c_concat'][0].shape
+        shape = (self.channels, h // 8, w // 8)
+        return sampler.sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
+
+    def decode_first_stage(self, z: torch.Tensor) -> torch.Tensor:
+        if self.first_stage_model is None:
+            raise NotImplementedError('VAE decoder (first_stage_config) is the next row after the sampler (SURVEY.md §8f rank 1)')
+        return self.first_stage_model.decode(z / self.scale_factor)
+
+
+class TestDiffuseModel(BaseMakeUpDiffuse):
+    """Reference Test* harness classes (diffmk/diffusion_makeup.py:308-411, diffmk/makeup_diffuse.py:413-464):
+    adds the sampling settings and ``log_results``' two DDIM passes."""
+
+    def __init__(self, saved_dir: str = './results', model_name: str = 'makeupdiffuse', img_name_key: str = 'name',
+                 unconditional_guidance_scale: float = 9, ddim_steps: int = 50, ddim_eta: float = 0.0, sample: bool = True,
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.unconditional_guidance_scale = unconditional_guidance_scale
+        self.ddim_steps, self.ddim_eta, self.sample = ddim_steps, ddim_eta, sample
+        self.saved_dir, self.model_name, self.img_name_key = saved_dir, model_name, img_name_key
+        self.clamp = True
+        self.rescale = True
+        self.test_pairs: list = []
+
+    @torch.no_grad()
+    def log_results(self, batch: dict, batch_idx: int, x_T: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """The sampler calls of reference log_results (:391-410): a plain 50-step pass and a CFG pass whose
+        unconditional branch keeps the SAME hint (uc_cat = c_cat, :401).  Returns latents (and decoded images
+        once a first_stage_model is attached); the teacher / reconstruction rows are out of scope."""
+        use_ddim = self.ddim_steps is not None
+        log: Dict[str, torch.Tensor] = {}
+        _, c = self.get_input(batch, self.first_stage_key)
+        c_cat, c_txt = c['c_concat'][0], c['c_crossattn'][0]
+        src, ref = torch.chunk(c_cat, 2, dim=1)
+        log['control_src'] = src * 2.0 - 1.0
+        log['control_ref'] = ref * 2.0 - 1.0
+        b = c_cat.shape[0]
+        extra = {} if x_T is None else {'x_T': x_T}
+        cond = {'c_concat': [c_cat], 'c_crossattn': [c_txt]}
+        if self.sample:
+            samples, _ = self.sample_log(cond=cond, batch_size=b, ddim=use_ddim, ddim_steps=self.ddim_steps,
+                                         eta=self.ddim_eta, **extra)
+            log['samples_latent'] = samples
+            if self.first_stage_model is not None:
+                log['samples'] = self.decode_first_stage(samples)
+        if self.unconditional_guidance_scale > 1.0:
+            uc_full = {'c_concat': [c_cat], 'c_crossattn': [self.get_unconditional_conditioning(b)]}
+            samples_cfg, _ = self.sample_log(cond=cond, batch_size=b, ddim=use_ddim, ddim_steps=self.ddim_steps,
+                                             eta=self.ddim_eta, unconditional_guidance_scale=self.unconditional_guidance_scale,
+                                             unconditional_conditioning=uc_full, **extra)
+            name = f'samples_cfg_scale_{self.unconditional_guidance_scale:.2f}'
+            log[name + '_latent'] = samples_cfg
+            if self.first_stage_model is not None:
+                log[name] = self.decode_first_stage(samples_cfg)
+        return log
+
+    def test_step(self, batch: dict, batch_idx: int) -> Dict[str, torch.Tensor]:
+        images = self.log_results(batch, batch_idx)
+        for k in images:
+            if isinstance(images[k], torch.Tensor):
+                images[k] = images[k].detach().cpu()
+                if self.clamp and not k.endswith('_latent'):
+                    images[k] = torch.clamp(images[k], -1.0, 1.0)
+        return images

@@ -1,0 +1,75 @@
+"""Multi-GPU: one process per GPU, batch-sharded replicas, ONE collective after the loop.
+
+Every op on the path is per-sample, so ranks never talk inside the 50-step loop; the only exchange is the
+all-gather of the finished latents/images.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the
+CPU tests of this host logic."""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n_items for `rank`; the first n_items % world ranks get one extra."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f'bad rank/world {rank}/{world}')
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun env; initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def gather_shards(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """All-gather per-rank batch shards (possibly ragged by one) into the full [n_total, ...] tensor, in
+    global sample order, on every rank.  Single collective: shards are padded to the largest shard."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if local.shape[0] != n_total:
+            raise ValueError('single-process gather: shard is not the whole batch')
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_range(n_total, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f'rank {rank}: shard has {local.shape[0]} samples, expected {hi - lo}')
+    cap = -(-n_total // world)
+    pad = local
+    if local.shape[0] < cap:
+        pad = torch.cat([local, local.new_zeros((cap - local.shape[0],) + tuple(local.shape[1:]))])
+    out = local.new_empty((world * cap,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        l, h = shard_range(n_total, r, world)
+        parts.append(out[r * cap: r * cap + (h - l)])
+    return torch.cat(parts)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

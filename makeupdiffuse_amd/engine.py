@@ -252,6 +252,18 @@ class MkdEngine:
                                            C.c_void_p(_stream())), 'mkd_sample')
         return out
 
+    def eps_profile(self, x: torch.Tensor, t: torch.Tensor) -> Dict[str, Dict[str, float]]:
+        """One eps with HIP events around every launch group -> {kernel class: {ms, flops, launches}}."""
+        x = _f32c(x, self.device)
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty((self.batch, self.cfg.out_channels, *self.latent_hw), device=self.device, dtype=torch.float32)
+        n = self.lib.mkd_kind_count()
+        ms = (C.c_double * n)(); fl = (C.c_double * n)(); ln = (C.c_int * n)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_eps_profile(self._ctx, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(_stream()), ms, fl, ln), 'mkd_eps_profile')
+        return {self.lib.mkd_kind_name(k).decode(): {'ms': ms[k], 'flops': fl[k], 'launches': ln[k]} for k in range(n)}
+
     # ---- introspection -----------------------------------------------------------------------------
     def eps_flops(self) -> float:
         return float(self.lib.mkd_eps_flops(self._ctx))

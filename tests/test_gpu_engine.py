@@ -125,5 +125,7 @@ def test_full_size_eps_vs_oracle():
     eng.prepare(hint, ctx)
     r, c = check_eps(eng.eps(x, t), ref, what='full-size eps')
     print(f'full-size eps: rel-L2 {r:.4e} cos {c:.6f} launches {eng.eps_launches()} GFLOP {eng.eps_flops() / 1e9:.1f}')
-    assert abs(eng.eps_flops() / 2e9 - 121.42) < 1.5     # 121.42 GMAC per sample per eval
+    # 121.42 GMAC per sample per eval, minus what mkd_prepare caches once per batch:
+    # hint block 1.87 GMAC + cross-attention K/V projections 2.16 GMAC -> 117.39 GMAC executed per eval
+    assert abs(eng.eps_flops() / 2e9 - 117.39) < 0.05
     eng.close()
