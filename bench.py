@@ -26,9 +26,25 @@ from makeupdiffuse_amd import dist as mdist  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-MFMA_KINDS = ('gemm_conv3x3_tn128', 'gemm_conv3x3_tn64', 'gemm_linear_tn128', 'gemm_linear_tn64', 'attention')
+MFMA_PREFIXES = ('gemm_', 'attention')
 
 
 def synth_inputs(lo, hi, res, ctx_dim, device):
@@ -74,16 +90,17 @@ def cpu_baseline(sd_cpu, res, x1, hint1, ctx1, gpu_eps1, n_evals, ddim_steps):
     """The reference's CPU path cannot run here (ldm/cldm absent), so this times the fp32 torch RESTATEMENT
     (oracle/, kind "port") on the host cores: BASELINE config 1 (B=1, fp32) bounded to n_evals eps evaluations."""
     from oracle import nets, sampler
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     cfg = nets.FULL
     cond = {'c_crossattn': [ctx1], 'c_concat': [hint1]}
     t = torch.tensor([981])
     times, ref = [], None
-    for _ in range(n_evals):
+    for i in range(n_evals):
         t0 = time.perf_counter()
         ref = sampler.apply_model(sd_cpu, cfg, x1, t, cond)
         times.append(time.perf_counter() - t0)
+        log(f'cpu baseline eval {i + 1}/{n_evals}: {times[-1]:.2f} s on {threads} threads')
     s_eval = float(np.median(times))
     rel = float(((gpu_eps1.cpu() - ref).norm() / ref.norm()).item())
     cos = float(torch.nn.functional.cosine_similarity(gpu_eps1.cpu().flatten(), ref.flatten(), dim=0).item())
@@ -103,8 +120,9 @@ def main():
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--cfg', action='store_true', help='classifier-free guidance 9.0 (2 evals / step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-evals', type=int, default=3)
+    ap.add_argument('--cpu-evals', type=int, default=2)
     ap.add_argument('--graph', type=int, default=0)
+    ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
     args = ap.parse_args()
 
     rank, world, local = mdist.init_from_env()
@@ -118,7 +136,9 @@ def main():
     cfg = NetConfig()
     eng = MkdEngine(cfg, dev)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    log(f'rank {rank}/{world}: generating 1.22 G synthetic weights on {dev}')
     sd_cpu = gen_weights(eng, seed=0, keep_cpu=want_cpu)
+    log('weights loaded')
 
     B = args.batch
     n_total = B * world
@@ -136,8 +156,11 @@ def main():
                          cfg_scale=cfg_scale, use_graph=bool(args.graph))
         return mdist.gather_shards(lat, n_total)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         out = one_step()
+        torch.cuda.synchronize()
+        log(f'warmup step {i + 1}/{args.warmup}: {time.perf_counter() - t_w:.2f} s')
     mdist.barrier(); torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -149,6 +172,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = mdist.max_over_ranks(dt, dev)
     assert torch.isfinite(out).all(), 'non-finite latents'
+    log(f'timed {args.steps} steps in {dt:.2f} s')
 
     if rank == 0:
         evals_per_step = args.ddim_steps
@@ -158,9 +182,9 @@ def main():
         tt = torch.full((eng.batch,), int(sch.ddim_timesteps[-1]), dtype=torch.int64, device=dev)
         x_in = torch.cat([x_T, x_T]) if args.cfg else x_T
         eng.eps_profile(x_in, tt)
-        prof = eng.eps_profile(x_in, tt)
+        prof = eng.eps_profile(x_in, tt, csv_path=args.ops_csv)
         tot_ms = sum(v['ms'] for v in prof.values())
-        dom = max((k for k in prof if k in MFMA_KINDS), key=lambda k: prof[k]['ms'])
+        dom = max((k for k in prof if k.startswith(MFMA_PREFIXES)), key=lambda k: prof[k]['ms'])
         d = prof[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',

@@ -113,11 +113,12 @@ double  mkd_eps_flops(const mkd_ctx* ctx);
 /* Number of kernel launches of one mkd_eps at the prepared shape. */
 int     mkd_eps_launches(const mkd_ctx* ctx);
 /* Kernel classes of the launch plan, and one mkd_eps with a hipEvent pair around every launch group:
- * per-class device milliseconds, executed FLOPs and launch counts (arrays of mkd_kind_count()). Synchronous. */
+ * per-class device milliseconds, executed FLOPs and launch counts (arrays of mkd_kind_count()). Synchronous.
+ * csv_path (host string, may be NULL): also write one line per launch group (op,kind,label,ms,gflop). */
 int mkd_kind_count(void);
 const char* mkd_kind_name(int kind);
 int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream,
-                    double* ms_per_kind, double* flops_per_kind, int* launches_per_kind);
+                    double* ms_per_kind, double* flops_per_kind, int* launches_per_kind, const char* csv_path);
 /* Bytes of device memory held by the context (weights + workspace). */
 int64_t mkd_device_bytes(const mkd_ctx* ctx);
 

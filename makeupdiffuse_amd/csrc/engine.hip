@@ -13,6 +13,7 @@
 #include "../../include/mkd.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -66,9 +67,9 @@ struct Epi {
 
 typedef std::function<int(hipStream_t)> OpFn;
 
-enum OpKind { K_GEMM_CONV128 = 0, K_GEMM_CONV64, K_GEMM_LIN128, K_GEMM_LIN64, K_GROUPNORM, K_LAYERNORM, K_ATTENTION,
-              K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
-const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_tn128", "gemm_conv3x3_tn64", "gemm_linear_tn128", "gemm_linear_tn64",
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 4, K_GROUPNORM = 8, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_128x128", "gemm_conv3x3_128x64", "gemm_conv3x3_64x128", "gemm_conv3x3_64x64",
+                                         "gemm_linear_128x128", "gemm_linear_128x64", "gemm_linear_64x128", "gemm_linear_64x64",
                                          "groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
 
 }  // namespace
@@ -103,7 +104,7 @@ struct mkd_ctx {
     float* gn_ws = nullptr; size_t gn_ws_bytes = 0, gn_need = 0;
     std::vector<OpFn> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
-    std::vector<int> kind_eps; std::vector<double> opflops_eps; std::vector<int> oplaunch_eps;
+    std::vector<int> kind_eps; std::vector<double> opflops_eps; std::vector<int> oplaunch_eps; std::vector<std::string> label_eps;
     bool dry = false; bool counting_eps = false;
     std::map<std::string, Tensor> kv_cache;       // transformer prefix -> [B*77, 2d]
     Tensor hint_emb;
@@ -375,11 +376,11 @@ struct mkd_ctx {
     }
 
     // ---- plan building ------------------------------------------------------------------------------
-    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops, int kind = K_MISC) {
+    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops, int kind = K_MISC, const std::string& label = "") {
         if (counting_eps) { launches_eps += launches; flops_eps += flops; }
         if (!dry) {
             plan.push_back(std::move(f));
-            if (counting_eps) { kind_eps.push_back(kind); opflops_eps.push_back(flops); oplaunch_eps.push_back(launches); }
+            if (counting_eps) { kind_eps.push_back(kind); opflops_eps.push_back(flops); oplaunch_eps.push_back(launches); label_eps.push_back(label); }
         }
     }
     std::vector<OpFn>* cur_plan = nullptr;
@@ -399,7 +400,10 @@ struct mkd_ctx {
         mkd_ctx* self = this;
         push(*cur_plan, [self, a](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws; return launch_gemm(b, st); },
              s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
-             a.conv ? (a.N % 128 == 0 ? K_GEMM_CONV128 : K_GEMM_CONV64) : (a.N % 128 == 0 ? K_GEMM_LIN128 : K_GEMM_LIN64));
+             (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K),
+             "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
+             " stride=" + std::to_string(a.stride) + " up=" + std::to_string(a.up) + " splitk=" + std::to_string(s) +
+             " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32));
     }
     void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
         GemmArgs a; memset(&a, 0, sizeof(a));
@@ -426,19 +430,21 @@ struct mkd_ctx {
         Tensor t = in;
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out](hipStream_t st) {
             return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws, st);
-        }, 2, 0.0, K_GROUPNORM);
+        }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
-        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0, K_LAYERNORM);
+        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0, K_LAYERNORM,
+             "rows=" + std::to_string(rows) + " d=" + std::to_string(d));
     }
     void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
                  int B_, int Tq, int Tk, int heads, int dh) {
         const float scale = 1.0f / sqrtf((float)dh);
         push(*cur_plan, [=](hipStream_t st) { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B_, Tq, Tk, heads, dh, scale, st); },
-             1, 4.0 * B_ * heads * (double)Tq * Tk * dh, K_ATTENTION);
+             1, 4.0 * B_ * heads * (double)Tq * Tk * dh, K_ATTENTION,
+             "B=" + std::to_string(B_) + " Tq=" + std::to_string(Tq) + " Tk=" + std::to_string(Tk) + " heads=" + std::to_string(heads) + " dh=" + std::to_string(dh));
     }
     void op_geglu(const bf16_t* x, bf16_t* y, int rows, int inner) {
-        push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0, K_GEGLU);
+        push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0, K_GEGLU, "rows=" + std::to_string(rows) + " inner=" + std::to_string(inner));
     }
     void op_copy(const bf16_t* src, int ld_src, bf16_t* dst, int ld_dst, int rows, int cols) {
         push(*cur_plan, [=](hipStream_t st) { return launch_copy_strided(src, ld_src, dst, ld_dst, rows, cols, st); }, 1, 0.0);
@@ -638,7 +644,7 @@ struct mkd_ctx {
     void build_eps_plan() {
         cur_plan = &plan_eps;
         counting_eps = true;
-        flops_eps = 0; launches_eps = 0; kind_eps.clear(); opflops_eps.clear(); oplaunch_eps.clear();
+        flops_eps = 0; launches_eps = 0; kind_eps.clear(); opflops_eps.clear(); oplaunch_eps.clear(); label_eps.clear();
         mkd_ctx* self = this;
         std::vector<Tensor> cn_feats, hs;
         Tensor cn_mid, u_mid;
@@ -792,7 +798,8 @@ struct mkd_ctx {
     }
 
     // one eps with a hipEvent pair around every plan op: per-kernel-class device time (bench roofline)
-    int eps_profile(const float* x, const int64_t* t, float* out, hipStream_t stream, double* ms, double* flops, int* launches) {
+    int eps_profile(const float* x, const int64_t* t, float* out, hipStream_t stream, double* ms, double* flops, int* launches,
+                    const char* csv_path = nullptr) {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps_profile before mkd_prepare");
         io_x = x; io_t = t; io_out = out;
         const size_t n = plan_eps.size();
@@ -806,11 +813,15 @@ struct mkd_ctx {
         }
         if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipStreamSynchronize");
         for (int k = 0; k < K_COUNT; ++k) { ms[k] = 0; flops[k] = 0; launches[k] = 0; }
+        FILE* csv = (csv_path && !rc) ? fopen(csv_path, "w") : nullptr;
+        if (csv) fprintf(csv, "op,kind,label,ms,gflop\n");
         for (size_t i = 0; i < n && !rc; ++i) {
             float dt = 0.f;
             if (hipEventElapsedTime(&dt, ev[i], ev[i + 1]) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime"); break; }
             ms[kind_eps[i]] += dt; flops[kind_eps[i]] += opflops_eps[i]; launches[kind_eps[i]] += oplaunch_eps[i];
+            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kKindNames[kind_eps[i]], label_eps[i].c_str(), dt, opflops_eps[i] / 1e9);
         }
+        if (csv) fclose(csv);
         for (auto& e : ev) hipEventDestroy(e);
         return rc;
     }
@@ -948,9 +959,9 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
 int mkd_kind_count(void) { return K_COUNT; }
 const char* mkd_kind_name(int kind) { return (kind >= 0 && kind < K_COUNT) ? kKindNames[kind] : nullptr; }
 int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream, double* ms_per_kind,
-                    double* flops_per_kind, int* launches_per_kind) {
+                    double* flops_per_kind, int* launches_per_kind, const char* csv_path) {
     if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile: null argument");
-    return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind);
+    return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind, csv_path);
 }
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }

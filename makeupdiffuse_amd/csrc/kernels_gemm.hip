@@ -13,7 +13,8 @@
 //     wave-instruction, no VGPR round trip).  The LDS image is lane-linear, so the bank-conflict
 //     XOR swizzle is applied to the per-lane SOURCE chunk and again on the ds_read_b128 side;
 //     padding / out-of-range rows / conv halo read from a zero page instead of branching.
-//   * 2 LDS stages, one barrier per K-step: loads of step k+1 fly under the MFMAs of step k.
+//   * 3-4 stage LDS ring, one raw s_barrier per K-step, counted s_waitcnt vmcnt(N): 2-3 K-steps of
+//     global_load_lds stay in flight across every barrier (the small-M layers are latency-bound).
 //   * the product is computed transposed (D = W_tile . X_tile^T with v_mfma_f32_16x16x32_bf16) so
 //     each lane ends with 4 CONSECUTIVE n for one m: 8-byte bf16x4 stores, float4 bias loads.
 //   * small-M layers (4x4 / 8x8 latents) are weight-bandwidth bound: split-K over blockIdx.z with
@@ -22,7 +23,6 @@
 
 namespace {
 
-constexpr int TM = 128;
 constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -32,43 +32,68 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, f32x4 v) {
-    if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-        v += b;
-    }
-    if (p.rowbias) {
-        const f32x4 b = *(const f32x4*)(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);
-        v += b;
-    }
-    v *= p.scale;
-    if (p.R) {
-        const U16x4 r = *(const U16x4*)(p.R + (size_t)m * p.ldr + n);
+// branch-free select of a load source, made opaque so the compiler keeps ONE global_load_lds per call site
+// (a duplicated load would break the exact loads-per-tile count the counted vmcnt waits rely on).
+__device__ __forceinline__ const void* select_src(const void* real, const void* zero, bool ok) {
+    unsigned long long v = ok ? (unsigned long long)real : (unsigned long long)zero;
+    asm volatile("" : "+v"(v));
+    return (const void*)v;
+}
+
+struct Epilogue {
+    const float* bias; const float* rowbias; int ldrb; int rpb;
+    const bf16_t* R; int ldr; float scale; int act; void* C; int ldc; int out_f32;
+};
+
+__device__ __forceinline__ Epilogue make_epilogue(const GemmArgs& p) {
+    return Epilogue{p.bias, p.rowbias, p.ldrb, p.rows_per_batch, p.R, p.ldr, p.scale, p.act, p.C, p.ldc, p.out_f32};
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue e, int m, int n, f32x4 v) {
+    if (e.bias) v += *(const f32x4*)(e.bias + n);
+    if (e.rowbias) v += *(const f32x4*)(e.rowbias + (size_t)(m / e.rpb) * e.ldrb + n);
+    v *= e.scale;
+    if (e.R) {
+        const U16x4 r = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r.v[j]);
     }
-    if (p.act == 1) {
+    if (e.act == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
     }
-    if (p.out_f32) {
-        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+    if (e.out_f32) {
+        *(f32x4*)((float*)e.C + (size_t)m * e.ldc + n) = v;
     } else {
         U16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o.v[j] = f32_to_bf16(v[j]);
-        *(U16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        *(U16x4*)((bf16_t*)e.C + (size_t)m * e.ldc + n) = o;
     }
 }
 
-template <int TN, int CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int CONV, int STAGES>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XS = TM * 128;          // bytes of one X stage (128 rows x 64 bf16)
+    constexpr int XS = TM * 128;          // bytes of one X stage (TM rows x 64 bf16)
     constexpr int WSB = TN * 128;         // bytes of one W stage
     constexpr int STAGE = XS + WSB;
     constexpr int WP = TN / 32;           // W pieces (1 KiB) per wave
     constexpr int NI = TN / 32;           // W fragments (16 rows) per wave
+    constexpr int XP = TM / 32;           // X pieces (1 KiB) per wave
+    constexpr int MI = TM / 32;           // X fragments (16 rows) per wave
+    constexpr int LPT = XP + WP;          // global_load_lds per wave per K-tile (exact)
+
+    // hoist the argument block into registers (keeps it out of scratch)
+    const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
+    const int lda = p.lda, ldw = p.ldw, M = p.M, N = p.N, K = p.K;
+    const int Hin = p.Hin, Win = p.Win, Cin = p.Cin, Hout = p.Hout, Wout = p.Wout, cstride = p.stride, up = p.up;
+    const int splitk = p.splitk, per = p.ksteps_per_split;
+    float* const ws = p.ws;
+    const Epilogue epi = make_epilogue(p);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,83 +101,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int wm = w >> 1, wn = w & 1;
     const int m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
-    const int nk_total = (p.K + BK - 1) / BK;
-    const int kt_begin = blockIdx.z * p.ksteps_per_split;
-    const int kt_end = min(nk_total, kt_begin + p.ksteps_per_split);
+    const int nk_total = (K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * per;
+    const int kt_end = min(nk_total, kt_begin + per);
 
     // ---- per-lane staging geometry -----------------------------------------------------------
     const int lrow = lane >> 3;                               // row inside a 1 KiB piece
     const int key = (4 * (w & 1) + (lane >> 4)) & 7;          // == ((tile_row >> 1) & 7) for every piece of this wave
     const int sc = (lane & 7) ^ key;                          // source 16-B chunk inside the 128-B K row
 
-    const bf16_t* xptr[4];
-    int xbase[4], uy0[4], ux0[4];
-    const int Hup = p.Hin << p.up, Wup = p.Win << p.up;
+    size_t xoff[XP];                   // LINEAR: element offset of the row;  CONV: pixel-index base of the sample
+    int uy0[XP], ux0[XP];              // CONV: top-left input coordinate of the 3x3 window (in upsampled space)
+    bool xok[XP];
+    const int Hup = Hin << up, Wup = Win << up;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XP; ++i) {
         const int m = m0 + 8 * (w + 4 * i) + lrow;
+        xok[i] = m < M;
         if (CONV) {
-            xptr[i] = nullptr;
-            if (m < p.M) {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw;
-                const int rem = m - b * hw;
-                const int oy = rem / p.Wout;
-                const int ox = rem - oy * p.Wout;
-                xbase[i] = b * p.Hin * p.Win;
-                uy0[i] = oy * p.stride - 1;
-                ux0[i] = ox * p.stride - 1;
-            } else {
-                xbase[i] = 0; uy0[i] = -(1 << 20); ux0[i] = -(1 << 20);
-            }
+            const int hw = Hout * Wout;
+            const int mm = xok[i] ? m : 0;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / Wout;
+            const int ox = rem - oy * Wout;
+            xoff[i] = (size_t)b * Hin * Win;
+            uy0[i] = oy * cstride - 1;
+            ux0[i] = ox * cstride - 1;
         } else {
-            xptr[i] = (m < p.M) ? p.A + (size_t)m * p.lda : nullptr;
-            xbase[i] = uy0[i] = ux0[i] = 0;
+            xoff[i] = (size_t)m * lda;
+            uy0[i] = ux0[i] = 0;
         }
     }
-    const bf16_t* wptr[WP];
+    size_t woff[WP];
+    bool wok[WP];
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
         const int n = n0 + 8 * (w + 4 * i) + lrow;
-        wptr[i] = (n < p.N) ? p.W + (size_t)n * p.ldw : nullptr;
+        wok[i] = n < N;
+        woff[i] = (size_t)n * ldw;
     }
 
     auto stage = [&](int buf, int kt) {
         char* xs = smem + buf * STAGE;
         char* wsm = xs + XS;
         const int k = kt * BK + sc * 8;
-        const bool kok = k < p.K;
+        const bool kok = k < K;
         int ci = 0, ky = 0, kx = 0;
         if (CONV) {
-            const int tap = k / p.Cin;
-            ci = k - tap * p.Cin;
+            const int tap = k / Cin;
+            ci = k - tap * Cin;
             ky = (tap * 11) >> 5;          // tap / 3 for tap in [0, 9)
             kx = tap - 3 * ky;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t* src = p.zero;
+        for (int i = 0; i < XP; ++i) {
+            const bf16_t* real;
+            bool ok;
             if (CONV) {
                 const int uy = uy0[i] + ky, ux = ux0[i] + kx;
-                if (kok && (unsigned)uy < (unsigned)Hup && (unsigned)ux < (unsigned)Wup)
-                    src = p.A + ((size_t)(xbase[i] + (uy >> p.up) * p.Win + (ux >> p.up)) * p.lda + ci);
+                ok = kok && xok[i] && (unsigned)uy < (unsigned)Hup && (unsigned)ux < (unsigned)Wup;
+                real = gA + ((xoff[i] + (size_t)((uy >> up) * Win + (ux >> up))) * lda + ci);
             } else {
-                if (kok && xptr[i]) src = xptr[i] + k;
+                ok = kok && xok[i];
+                real = gA + xoff[i] + k;
             }
-            glds16(src, xs + (w + 4 * i) * 1024);
+            glds16(select_src(real, gZ, ok), xs + (w + 4 * i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            const bf16_t* src = (kok && wptr[i]) ? wptr[i] + k : p.zero;
-            glds16(src, wsm + (w + 4 * i) * 1024);
-        }
+        for (int i = 0; i < WP; ++i)
+            glds16(select_src(gW + woff[i] + k, gZ, kok && wok[i]), wsm + (w + 4 * i) * 1024);
     };
 
-    f32x4 acc[NI][4];
+    f32x4 acc[NI][MI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
@@ -163,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int chunk = 4 * kk + fq;
-            bf16x8 xf[4], wf[NI];
+            bf16x8 xf[MI], wf[NI];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = wm * 64 + mi * 16 + frow;
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * (TM / 2) + mi * 16 + frow;
                 xf[mi] = *(const bf16x8*)(xs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -177,67 +202,132 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
     };
 
-    if (kt_begin < kt_end) {
-        stage(0, kt_begin);
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int buf = (kt - kt_begin) & 1;
-            __syncthreads();               // tile kt landed (vmcnt(0) + barrier); buf^1 is free again
-            if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
+    // ---- K loop: STAGES-deep LDS ring, STAGES-1 tiles of global_load_lds in flight across each barrier ----
+    // Every wave issues exactly LPT loads per tile, in order, so "tile i landed" == "at most LPT * (tiles
+    // issued after i) of my loads are still outstanding": a counted s_waitcnt, never a full drain.
+    const int ntile = kt_end - kt_begin;
+    if (ntile > 0) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < ntile) stage(s, kt_begin + s);
+        int buf = 0;                               // ring slot of tile i
+        int nxt = STAGES - 1;                      // ring slot the next prefetch goes to
+        for (int i = 0; i < ntile; ++i) {
+            const int after = min(STAGES - 2, ntile - 1 - i);      // tiles issued after tile i
+            if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
+            else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // tile i visible to all waves; slot of tile i-1 is free
+            asm volatile("" ::: "memory");
+            if (i + STAGES - 1 < ntile) stage(nxt, kt_begin + i + STAGES - 1);
             compute(buf);
+            buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
         }
     }
 
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + frow;
-        if (m >= p.M) continue;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * (TM / 2) + mi * 16 + frow;
+        if (m >= M) continue;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + wn * (TN / 2) + ni * 16 + 4 * fq;
-            if (n >= p.N) continue;
-            if (p.splitk > 1) {
-                *(f32x4*)(p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + n) = acc[ni][mi];
+            if (n >= N) continue;
+            if (splitk > 1) {
+                *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
             } else {
-                epilogue_store(p, m, n, acc[ni][mi]);
+                epilogue_store(epi, m, n, acc[ni][mi]);
             }
         }
     }
 }
 
+// split-K reduce + epilogue: thread = (row m, 4 columns); slabs summed 4 at a time with independent loads.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) {
-    const int nq = p.N >> 2;
-    const int64_t total = (int64_t)p.M * nq;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int m = (int)(idx / nq);
-        const int n = (int)(idx - (int64_t)m * nq) << 2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < p.splitk; ++z) v += *(const f32x4*)(p.ws + ((size_t)z * p.M + m) * p.N + n);
-        epilogue_store(p, m, n, v);
+    const int n = (blockIdx.x * 64 + (threadIdx.x & 63)) << 2;
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n >= p.N || m >= p.M) return;
+    const size_t slab = (size_t)p.M * p.N;
+    const float* src = p.ws + (size_t)m * p.N + n;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= p.splitk; z += 4) {
+        const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
+        const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
+        const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
+        const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
+        v += (a + b) + (c + d);
     }
+    for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
+    epilogue_store(make_epilogue(p), m, n, v);
 }
 
 }  // namespace
 
-int gemm_pick_splitk(int M, int N, int K) {
-    const int tn = (N % 128 == 0) ? 128 : 64;
-    const int tiles = ((M + TM - 1) / TM) * ((N + tn - 1) / tn);
+struct GemmPlan { int tm, tn, splitk, per; };
+
+// Tile + split-K choice.  Large problems take the 128x128 tile (best FLOP per staged byte); problems that
+// cannot fill the 256 CUs that way step down to 128x64 / 64x64 tiles FIRST (more blocks, no extra traffic)
+// and only then split K (fp32 partial slabs cost 8 B per output element per slice).
+static GemmPlan gemm_plan(int M, int N, int K, int force_splitk) {
     const int nk = (K + BK - 1) / BK;
-    if (tiles >= 128 || nk < 4) return 1;
-    int s = 256 / tiles;
-    if (s > nk / 2) s = nk / 2;
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
-    return s;
+    const bool n128 = (N % 128 == 0);
+    auto tiles = [&](int tm, int tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+    GemmPlan g{128, n128 ? 128 : 64, 1, nk};
+    const int want = 224;
+    if (tiles(g.tm, g.tn) < want) {
+        if (tiles(128, 64) >= want || M <= 64) { g.tn = 64; g.tm = (M <= 64 ? 64 : 128); }
+        else { g.tm = 64; g.tn = 64; }
+    }
+    int s = 1;
+    if (force_splitk > 0) s = force_splitk;
+    else {
+        const int t = tiles(g.tm, g.tn);
+        if (t < 160 && nk >= 8) {
+            s = (256 + t - 1) / t;
+            if (s > nk / 4) s = nk / 4;      // >= 4 K-steps per slice
+            if (s > 16) s = 16;
+            if (s < 1) s = 1;
+        }
+    }
+    if (s > nk) s = nk;
+    g.per = (nk + s - 1) / s;
+    g.splitk = (nk + g.per - 1) / g.per;
+    return g;
+}
+
+int gemm_pick_splitk(int M, int N, int K) { return gemm_plan(M, N, K, 0).splitk; }
+
+// 0: 128x128, 1: 128x64, 3: 64x64 (m x n)
+int gemm_tile_index(int M, int N, int K) {
+    const GemmPlan g = gemm_plan(M, N, K, 0);
+    return (g.tm == 64 ? 2 : 0) + (g.tn == 64 ? 1 : 0);
 }
 
 size_t gemm_ws_bytes(int M, int N, int splitk) {
     return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+}
+
+template <int TM, int TN, int STAGES>
+static int launch_tile(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128);
+    static bool attr_set[2] = {false, false};
+    if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
+        hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                              : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, 0, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+        attr_set[a.conv ? 1 : 0] = true;
+    }
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, 1, STAGES>), grid, dim3(256), lds, stream, a);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, 0, STAGES>), grid, dim3(256), lds, stream, a);
+    return 0;
 }
 
 int launch_gemm(GemmArgs a, hipStream_t stream) {
@@ -249,31 +339,20 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (!a.out_f32 && (a.ldc % 4)) return mkd_fail(-1, "gemm: ldc must be a multiple of 4");
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
-    const int tn = (a.N % 128 == 0) ? 128 : 64;
-    const int nk = (a.K + BK - 1) / BK;
-    int s = a.splitk;
-    if (s <= 0) s = gemm_pick_splitk(a.M, a.N, a.K);
-    if (s > nk) s = nk;
-    int per = (nk + s - 1) / s;
-    s = (nk + per - 1) / per;
-    if (s > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
-    a.splitk = s;
-    a.ksteps_per_split = per;
-    dim3 grid((a.M + TM - 1) / TM, (a.N + tn - 1) / tn, s);
-    const size_t lds = 2 * (TM * 128 + tn * 128);
-    if (tn == 128) {
-        if (a.conv) hipLaunchKernelGGL((gemm_kernel<128, 1>), grid, dim3(256), lds, stream, a);
-        else        hipLaunchKernelGGL((gemm_kernel<128, 0>), grid, dim3(256), lds, stream, a);
-    } else {
-        if (a.conv) hipLaunchKernelGGL((gemm_kernel<64, 1>), grid, dim3(256), lds, stream, a);
-        else        hipLaunchKernelGGL((gemm_kernel<64, 0>), grid, dim3(256), lds, stream, a);
-    }
+    const GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk);
+    if (g.splitk > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
+    a.splitk = g.splitk;
+    a.ksteps_per_split = g.per;
+    dim3 grid((a.M + g.tm - 1) / g.tm, (a.N + g.tn - 1) / g.tn, g.splitk);
+    int rc;
+    if (g.tm == 128 && g.tn == 128) rc = launch_tile<128, 128, 3>(a, grid, stream);      // 96 KiB LDS, 1 block/CU
+    else if (g.tm == 128 && g.tn == 64) rc = launch_tile<128, 64, 3>(a, grid, stream);   // 72 KiB, 2 blocks/CU
+    else rc = launch_tile<64, 64, 4>(a, grid, stream);                                    // 64 KiB, 2 blocks/CU
+    if (rc) return rc;
     MKD_LAUNCH_CHECK("gemm_kernel");
-    if (s > 1) {
-        const int64_t total = (int64_t)a.M * (a.N / 4);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    if (g.splitk > 1) {
+        dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, a);
         MKD_LAUNCH_CHECK("splitk_epilogue_kernel");
     }
     return 0;

@@ -116,6 +116,91 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t*
     }
 }
 
+// Single-launch GroupNorm for slabs that stay cache-resident: one workgroup per (sample, chunk of `gpb`
+// groups whose channel span is a multiple of 8).  Pass 1 accumulates per-channel sums in registers, a
+// deterministic 3-stage LDS reduction folds them per group, pass 2 re-reads the slab (L2 hit) and applies.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
+                                                       int ld_out, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu, int hw,
+                                                       int C, int groups, int gpb) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];    // [2][T][8] then per-channel / per-group
+    const int cg = C / groups;
+    const int nch = gpb * cg;                 // channels of this block (multiple of 8)
+    const int V = nch >> 3;
+    const int P = 256 / V;
+    const int T = V * P;                      // active threads
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * nch;
+    const bool active = tid < T;
+    const int v = active ? tid % V : 0;
+    const int pl = active ? tid / V : 0;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
+    const bf16_t* xin = x + (size_t)b * hw * ld_in + c0 + v * 8;
+    if (active) {
+        for (int r = pl; r < hw; r += P) {
+            const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf16_to_f32(d.v[j]);
+                sum[j] += f; sq[j] += f * f;
+            }
+        }
+    }
+    float* ssum = s_red;                      // [T][8]
+    float* ssq = s_red + 256 * 8;             // [T][8]
+    float* csum = s_red + 2 * 256 * 8;        // [nch] per-channel totals
+    float* csq = csum + nch;
+    float* gstat = csq + nch;                 // [gpb][2] mean, rstd
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ssum[tid * 8 + j] = sum[j]; ssq[tid * 8 + j] = sq[j]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) {    // per-channel: fixed-order sum over the P pixel lanes
+        float a = 0.f, q = 0.f;
+        const int vv = c >> 3, jj = c & 7;
+        for (int p = 0; p < P; ++p) { a += ssum[(p * V + vv) * 8 + jj]; q += ssq[(p * V + vv) * 8 + jj]; }
+        csum[c] = a; csq[c] = q;
+    }
+    __syncthreads();
+    if (tid < gpb) {
+        float a = 0.f, q = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += csum[c]; q += csq[c]; }
+        const float n = (float)hw * (float)cg;
+        const float mean = a / n;
+        float var = q / n - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        gstat[tid * 2] = mean;
+        gstat[tid * 2 + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cl = v * 8 + j;
+        const int g = cl / cg;
+        const float a = gamma[c0 + cl] * gstat[g * 2 + 1];
+        sa[j] = a;
+        sb[j] = beta[c0 + cl] - gstat[g * 2] * a;
+    }
+    bf16_t* yout = y + (size_t)b * hw * ld_out + c0 + v * 8;
+    for (int r = pl; r < hw; r += P) {
+        const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf16_to_f32(d.v[j]) * sa[j] + sb[j];
+            if (silu) f = silu_f(f);
+            o.v[j] = f32_to_bf16(f);
+        }
+        *(U16x8*)(yout + (size_t)r * ld_out) = o;
+    }
+}
+
 // one wave per row; NV = vectors of 8 per lane (d <= 64*8*NV)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
@@ -184,6 +269,25 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
     if (C % 8 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C, ld must be multiples of 8");
     if (groups > GN_MAX_GROUPS || groups <= 0 || C % groups) return mkd_fail(-1, "groupnorm: bad group count");
     if (!partials) return mkd_fail(-1, "groupnorm: partials workspace missing");
+    // single-launch path: smallest group chunk whose channel span is a multiple of 8, slab small enough to
+    // be re-read from cache
+    {
+        const int cg = C / groups;
+        int gpb = 1;
+        while (gpb <= groups && ((gpb * cg) % 8 || groups % gpb)) ++gpb;
+        if (gpb <= groups) {
+            const int nch = gpb * cg;
+            const size_t slab = (size_t)hw * nch * sizeof(bf16_t);
+            if (nch / 8 <= 256 && slab <= (size_t)384 * 1024) {
+                const size_t lds = (size_t)(2 * 256 * 8 + 2 * nch + 2 * gpb) * sizeof(float);
+                dim3 grid(groups / gpb, batch);
+                hipLaunchKernelGGL(gn_fused_kernel, grid, dim3(256), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
+                                   hw, C, groups, gpb);
+                MKD_LAUNCH_CHECK("gn_fused_kernel");
+                return 0;
+            }
+        }
+    }
     const int V = C / 8;
     if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");
     int P = 256 / V;

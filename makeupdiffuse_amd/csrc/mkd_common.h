@@ -66,6 +66,7 @@ struct GemmArgs {
 // launchers (each only enqueues on `stream`)
 int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
 int  gemm_pick_splitk(int M, int N, int K);
+int  gemm_tile_index(int M, int N, int K);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
 size_t gemm_ws_bytes(int M, int N, int splitk);
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,

@@ -252,7 +252,7 @@ class MkdEngine:
                                            C.c_void_p(_stream())), 'mkd_sample')
         return out
 
-    def eps_profile(self, x: torch.Tensor, t: torch.Tensor) -> Dict[str, Dict[str, float]]:
+    def eps_profile(self, x: torch.Tensor, t: torch.Tensor, csv_path: Optional[str] = None) -> Dict[str, Dict[str, float]]:
         """One eps with HIP events around every launch group -> {kernel class: {ms, flops, launches}}."""
         x = _f32c(x, self.device)
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
@@ -261,7 +261,8 @@ class MkdEngine:
         ms = (C.c_double * n)(); fl = (C.c_double * n)(); ln = (C.c_int * n)()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mkd_eps_profile(self._ctx, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
-                                                C.c_void_p(out.data_ptr()), C.c_void_p(_stream()), ms, fl, ln), 'mkd_eps_profile')
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(_stream()), ms, fl, ln,
+                                                None if csv_path is None else csv_path.encode()), 'mkd_eps_profile')
         return {self.lib.mkd_kind_name(k).decode(): {'ms': ms[k], 'flops': fl[k], 'launches': ln[k]} for k in range(n)}
 
     # ---- introspection -----------------------------------------------------------------------------

@@ -49,7 +49,7 @@ SIGNATURES = {
     'mkd_sample': (_I, [_P, _P, _I, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _P, _I, _P]),
     'mkd_kind_count': (_I, []),
     'mkd_kind_name': (C.c_char_p, [_I]),
-    'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)]),
+    'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.c_char_p]),
     'mkd_eps_flops': (C.c_double, [_P]),
     'mkd_eps_launches': (_I, [_P]),
     'mkd_device_bytes': (_L, [_P]),

@@ -112,7 +112,7 @@ def test_missing_weight_is_loud():
 @pytest.mark.timeout(900)
 def test_full_size_eps_vs_oracle():
     """BASELINE full architecture (859.5 M + 361.3 M params), B=1, 256x256: one eps eval vs the fp32 CPU oracle."""
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     cfg = nets.FULL
     sd = nets.init_state_dict(cfg, seed=0)
     gen = torch.Generator().manual_seed(1)

@@ -99,7 +99,7 @@ def test_gemm_conv3x3(B, H, W_, Cin, Cout, stride, up, pad_ld, splitk):
 
 
 @pytest.mark.parametrize('B,hw,C,silu,eps,pad', [(2, 64, 320, 1, 1e-5, 0), (3, 256, 640, 0, 1e-6, 0), (2, 16, 2560, 1, 1e-5, 0),
-                                                (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0),
+                                                (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0), (1, 4096, 960, 1, 1e-5, 0), (2, 4096, 320, 0, 1e-5, 0),
                                                 (1, 64, 1920, 1, 1e-5, 0)])
 def test_groupnorm(B, hw, C, silu, eps, pad):
     lib = L()
