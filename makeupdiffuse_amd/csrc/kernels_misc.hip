@@ -93,6 +93,48 @@ __global__ void conv3x3_direct_kernel(const void* __restrict__ xin, int in_nchw_
     }
 }
 
+// ---- 3x3 conv with a tiny Cout (the UNet's final C -> 4): one wavefront per output pixel ---------------
+// lanes split the (tap, ci) reduction in 16-B vectors, COUT accumulators per lane, wave-shuffle tree at the end.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y_nchw,
+                                                             int batch, int H, int W, int Cin) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int npix = batch * H * W;
+    if (pix >= npix) return;
+    const int b = pix / (H * W);
+    const int rem = pix - b * H * W;
+    const int oy = rem / W, ox = rem - oy * W;
+    const int V = Cin >> 3;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int idx = lane; idx < 9 * V; idx += 64) {
+        const int tap = idx / V, v = idx - tap * V;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+        const U16x8 xv = *(const U16x8*)(x + ((size_t)(b * H + iy) * W + ix) * Cin + v * 8);
+        float xf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = bf16_to_f32(xv.v[j]);
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            const U16x8 wv = *(const U16x8*)(w + ((size_t)c * 9 + tap) * Cin + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c] += xf[j] * bf16_to_f32(wv.v[j]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        float a = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) y_nchw[(((size_t)b * COUT + c) * H + oy) * W + ox] = a + (bias ? bias[c] : 0.f);
+    }
+}
+
 // ---- fp32 [Cout,Cin,kh,kw] -> bf16 [Cout][kh][kw][Cin] ----------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int kh, int kw) {
     const int64_t total = (int64_t)Cout * Cin * kh * kw;
@@ -174,6 +216,13 @@ int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
                           int Cin, int Cout, int stride, hipStream_t stream) {
     if (stride != 1 && stride != 2) return mkd_fail(-1, "conv3x3_direct: stride must be 1 or 2");
+    if (!in_nchw_f32 && out_nchw_f32 && Cout == 4 && stride == 1 && act == 0 && !add && Cin % 8 == 0) {
+        const int npix = batch * Hin * Win;
+        hipLaunchKernelGGL(conv3x3_fewout_kernel<4>, dim3((npix + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
+                           (float*)y, batch, Hin, Win, Cin);
+        MKD_LAUNCH_CHECK("conv3x3_fewout_kernel");
+        return 0;
+    }
     const int Hout = (Hin + 2 - 3) / stride + 1, Wout = (Win + 2 - 3) / stride + 1;
     const int64_t total = (int64_t)batch * Hout * Wout * Cout;
     hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, stream, x, in_nchw_f32, w, bias,

@@ -140,7 +140,20 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
     for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
     const bf16_t* xin = x + (size_t)b * hw * ld_in + c0 + v * 8;
     if (active) {
-        for (int r = pl; r < hw; r += P) {
+        int r = pl;
+        for (; r + 3 * P < hw; r += 4 * P) {          // 4 independent 16-B loads in flight per thread
+            U16x8 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf16_to_f32(d[u].v[j]);
+                    sum[j] += f; sq[j] += f * f;
+                }
+        }
+        for (; r < hw; r += P) {
             const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -188,7 +201,24 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
         sb[j] = beta[c0 + cl] - gstat[g * 2] * a;
     }
     bf16_t* yout = y + (size_t)b * hw * ld_out + c0 + v * 8;
-    for (int r = pl; r < hw; r += P) {
+    int r = pl;
+    for (; r + 3 * P < hw; r += 4 * P) {
+        U16x8 d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            U16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = bf16_to_f32(d[u].v[j]) * sa[j] + sb[j];
+                if (silu) f = silu_f(f);
+                o.v[j] = f32_to_bf16(f);
+            }
+            *(U16x8*)(yout + (size_t)(r + u * P) * ld_out) = o;
+        }
+    }
+    for (; r < hw; r += P) {
         const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
         U16x8 o;
 #pragma unroll

@@ -1,0 +1,190 @@
+"""CPU: the host-side mirror of the reference interface (sampler API, config surface, schedule tables, sharding
+arithmetic) and the C ABI's symbol table.  No compute is run through libmkd here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from makeupdiffuse_amd import dist as mdist
+from makeupdiffuse_amd import lib as mlib
+from makeupdiffuse_amd.config import create_model, load_yaml
+from makeupdiffuse_amd.schedule import DDIMSchedule
+from oracle import nets, sampler
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = dict(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+             hint_widths=(16, 16, 32, 32, 32, 32, 64))
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    """include/mkd.h <-> libmkd.so <-> the ctypes table: same set of entry points."""
+    from makeupdiffuse_amd import build as mbuild
+    path = mbuild.build(verbose=False)
+    so = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, 'include', 'mkd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(mkd_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(mlib.SIGNATURES), declared ^ set(mlib.SIGNATURES)
+    for name in declared:
+        getattr(so, name)
+    so.mkd_abi_version.restype = ctypes.c_int
+    assert so.mkd_abi_version() == mlib.ABI_VERSION
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from makeupdiffuse_amd.engine import MkdEngine, NetConfig
+    with pytest.raises(mlib.MkdError):
+        MkdEngine(NetConfig(**SMALL))
+    lib = mlib.load()
+    cfg = NetConfig(**SMALL).to_c()
+    h = ctypes.c_void_p()
+    assert lib.mkd_ctx_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b'no CPU path' in lib.mkd_last_error() or b'HIP' in lib.mkd_last_error()
+
+
+def test_product_does_not_import_the_oracle():
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for base in ('makeupdiffuse_amd', 'diffmk', 'runs'):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith('.py'):
+                    assert not pat.search(open(os.path.join(dp, f)).read()), f'{dp}/{f} imports oracle/'
+
+
+# ---- schedule / config surface -----------------------------------------------------------------------------------
+def test_product_schedule_equals_oracle_schedule():
+    for S in (20, 50):
+        a = DDIMSchedule().make_ddim(S)
+        b = sampler.Schedule().make_ddim(S)
+        assert np.array_equal(a.ddim_timesteps, b.ddim_timesteps)
+        for n in ('ddim_alphas', 'ddim_alphas_prev', 'ddim_sigmas', 'ddim_sqrt_one_minus_alphas', 'alphas_cumprod',
+                  'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod'):
+            assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_yaml_surface_own_and_reference_style():
+    m = create_model(os.path.join(ROOT, 'diffmodels', 'test_diffusion_makeup.yaml'))
+    assert type(m).__name__ == 'TestDoubleControlModel'
+    assert m.ddim_steps == 50 and m.unconditional_guidance_scale == 9 and m.ddim_eta == 0.0
+    assert m.net_config.model_channels == 320 and tuple(m.net_config.channel_mult) == (1, 2, 4, 4)
+    assert m.net_config.hint_channels == 6 and m.net_config.context_dim == 768 and m.net_config.n_control == 13
+    assert m.parameterization == 'eps' and abs(m.scale_factor - 0.18215) < 1e-9 and m.only_mid_control is False
+    assert len(m.control_scales) == 13 and m.num_timesteps == 1000
+    cfg = load_yaml(os.path.join(ROOT, 'diffmodels', 'base_diffusion_makeup.yaml'))
+    assert cfg['model']['target'] == 'diffmk.diffusion_makeup.BaseDoubleControlModel'
+    with pytest.raises(mlib.MkdError):          # no engine until .cuda(): loud
+        m.apply_model(torch.zeros(1, 4, 8, 8), torch.zeros(1, dtype=torch.long),
+                      {'c_crossattn': [torch.zeros(1, 77, 768)], 'c_concat': [torch.zeros(1, 6, 64, 64)]})
+
+
+def test_get_input_builds_source_first_hint():
+    m = create_model(os.path.join(ROOT, 'diffmodels', 'test_diffusion_makeup.yaml'))
+    batch = {'src_img': torch.full((2, 3, 16, 16), 0.25), 'ref_img': torch.full((2, 3, 16, 16), 0.75),
+             'txt_emb': torch.randn(2, 77, 768)}
+    _, c = m.get_input(batch, 'jpg')
+    hint = c['c_concat'][0]
+    assert hint.shape == (2, 6, 16, 16) and hint.dtype == torch.float32
+    assert torch.all(hint[:, :3] == 0.25) and torch.all(hint[:, 3:] == 0.75)       # makeup_diffuse.py:56 (src, ref)
+    assert c['c_crossattn'][0].shape == (2, 77, 768)
+    with pytest.raises(NotImplementedError):
+        m.get_input({'src_img': batch['src_img'], 'ref_img': batch['ref_img'], 'txt': ['makeup transfer'] * 2}, 'jpg')
+
+
+# ---- sampler host logic against the oracle, with a stand-in eps model ----------------------------------------------
+class _OracleBackedModel:
+    """Duck-typed `model` the samplers need whose apply_model is the CPU oracle: lets the host
+    logic of DDIMSampler / MKDDIMSampler be checked on CPU.  Test scaffolding only."""
+
+    def __init__(self):
+        self.cfg = nets.NetConfig(**SMALL)
+        self.sd = nets.init_state_dict(self.cfg, seed=11)
+        sch = DDIMSchedule()
+        self.num_timesteps = sch.num_timesteps
+        self.parameterization = 'eps'
+        self.device = torch.device('cpu')
+        for n in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_one_minus_alphas_cumprod'):
+            setattr(self, n, getattr(sch, n))
+        self.calls = []
+
+    def apply_model(self, x, t, c):
+        self.calls.append(x.shape[0])
+        return sampler.apply_model(self.sd, self.cfg, x, t, c)
+
+
+@pytest.fixture(scope='module')
+def gold():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'small_eps.npz'))
+    return {k: torch.from_numpy(g[k]) for k in g.files if k != 'seed_weights'}
+
+
+def test_mkddim_reconstruct_and_step_match_oracle(gold):
+    from diffmk.cddim import MKDDIMSampler
+    torch.set_num_threads(4)
+    model = _OracleBackedModel()
+    s = MKDDIMSampler(model)
+    s.make_schedule(ddim_num_steps=5, verbose=False)
+    cond = {'c_crossattn': [gold['ctx']], 'c_concat': [gold['hint']]}
+    out = s.reconstruct(gold['x'], cond, t_start=5)
+    assert torch.allclose(out, gold['x5'], rtol=1e-4, atol=1e-5)
+    seen = []
+    out3 = s.reconstruct(gold['x'], cond, t_start=3, callback=seen.append)
+    assert seen == [0, 1, 2]
+    sch = sampler.Schedule().make_ddim(5)
+    ref3 = sampler.reconstruct(sampler.make_eps_fn(model.sd, model.cfg), sch, gold['x'], cond, 3)
+    assert torch.allclose(out3, ref3, rtol=1e-4, atol=1e-5)
+    # CFG: ONE apply_model call on 2B, uncond first (cddim.py:18-40)
+    model.calls.clear()
+    uc = {'c_crossattn': [gold['uctx']], 'c_concat': [gold['hint']]}
+    outc = s.reconstruct(gold['x'], cond, t_start=5, unconditional_guidance_scale=9.0, unconditional_conditioning=uc)
+    assert model.calls == [4] * 5
+    assert torch.allclose(outc, gold['x5_cfg'], rtol=1e-3, atol=1e-4)
+    t = torch.full((2,), int(s.ddim_timesteps[4]), dtype=torch.long)
+    xp, x0 = s.denoising_step(gold['x'], cond, t, index=4)
+    rp, r0 = sampler.denoising_step(sampler.make_eps_fn(model.sd, model.cfg), sch, gold['x'], cond, t, 4)
+    assert torch.allclose(xp, rp, rtol=1e-5, atol=1e-6) and torch.allclose(x0, r0, rtol=1e-5, atol=1e-6)
+
+
+def test_sampler_rejects_what_the_reference_path_never_uses(gold):
+    from diffmk.cddim import MKDDIMSampler
+    model = _OracleBackedModel()
+    s = MKDDIMSampler(model)
+    s.make_schedule(ddim_num_steps=5, verbose=False)
+    cond = {'c_crossattn': [gold['ctx']], 'c_concat': [gold['hint']]}
+    t = torch.full((2,), 801, dtype=torch.long)
+    with pytest.raises(NotImplementedError):
+        s.denoising_step(gold['x'], cond, t, index=4, dynamic_threshold=0.5)        # cddim.py:70-71
+    with pytest.raises(NotImplementedError):
+        s.denoising_step(gold['x'], cond, t, index=4, quantize_denoised=True)
+    with pytest.raises(AssertionError):                                              # cddim.py:21 dict/dict check
+        s.denoising_step(gold['x'], cond, t, index=4, unconditional_guidance_scale=2.0,
+                         unconditional_conditioning=[gold['uctx']])
+
+
+def test_ddim_sampler_full_loop_from_x_T(gold):
+    from makeupdiffuse_amd.ddim import DDIMSampler
+    torch.set_num_threads(4)
+    model = _OracleBackedModel()
+    s = DDIMSampler(model)
+    cond = {'c_crossattn': [gold['ctx']], 'c_concat': [gold['hint']]}
+    out, inter = s.sample(5, 2, (4, 8, 8), cond, verbose=False, eta=0.0, x_T=gold['x'])
+    assert torch.allclose(out, gold['x5'], rtol=1e-4, atol=1e-5)
+    assert len(inter['x_inter']) >= 2
+
+
+# ---- batch sharding ------------------------------------------------------------------------------------------------
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 64, 352):
+        for world in (1, 2, 3, 8):
+            spans = [mdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        mdist.shard_range(8, 2, 2)
