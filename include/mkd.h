@@ -133,6 +133,8 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
                   void* C, int ldc, int out_f32, int M, int N, int K,
                   int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
                   int stride, int up, int splitk, void* stream);
+/* Tuner / tests only: force the GEMM tile configuration (index into the table in kernels_gemm.hip; -1 = heuristic). */
+int mkd_gemm_force_tile(int cfg);
 /* GroupNorm(32 groups, fp32 statistics) [+SiLU] over NHWC bf16 (pixel stride ld_in). */
 int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps,
                   int silu, uint16_t* y, int ld_out, int batch, int hw, int C, int groups, void* stream);

@@ -67,9 +67,11 @@ struct Epi {
 
 typedef std::function<int(hipStream_t)> OpFn;
 
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 4, K_GROUPNORM = 8, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
-const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_128x128", "gemm_conv3x3_128x64", "gemm_conv3x3_64x128", "gemm_conv3x3_64x64",
-                                         "gemm_linear_128x128", "gemm_linear_128x64", "gemm_linear_64x128", "gemm_linear_64x64",
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 6, K_GROUPNORM = 12, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_256x128", "gemm_conv3x3_128x128_s3", "gemm_conv3x3_128x128_s2", "gemm_conv3x3_128x64",
+                                         "gemm_conv3x3_64x128", "gemm_conv3x3_64x64",
+                                         "gemm_linear_256x128", "gemm_linear_128x128_s3", "gemm_linear_128x128_s2", "gemm_linear_128x64",
+                                         "gemm_linear_64x128", "gemm_linear_64x64",
                                          "groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
 
 }  // namespace
@@ -394,16 +396,17 @@ struct mkd_ctx {
     void op_gemm(GemmArgs a) {
         a.zero = zero_page;
         a.splitk = 0;
-        const int s = gemm_pick_splitk(a.M, a.N, a.K);
+        const int s = gemm_pick_splitk(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
         const size_t need = gemm_ws_bytes(a.M, a.N, s);
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
         push(*cur_plan, [self, a](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws; return launch_gemm(b, st); },
              s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
-             (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K),
+             (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0),
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
              " stride=" + std::to_string(a.stride) + " up=" + std::to_string(a.up) + " splitk=" + std::to_string(s) +
-             " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32));
+             " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32) + " Hin=" + std::to_string(a.Hin) +
+             " Win=" + std::to_string(a.Win) + " Cin=" + std::to_string(a.Cin) + " Hout=" + std::to_string(a.Hout) + " Wout=" + std::to_string(a.Wout));
     }
     void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
         GemmArgs a; memset(&a, 0, sizeof(a));
@@ -956,6 +959,7 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
     return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
                        (hipStream_t)stream);
 }
+int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
 int mkd_kind_count(void) { return K_COUNT; }
 const char* mkd_kind_name(int kind) { return (kind >= 0 && kind < K_COUNT) ? kKindNames[kind] : nullptr; }
 int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream, double* ms_per_kind,
@@ -995,7 +999,7 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
     a.R = R; a.ldr = ldr; a.scale = scale; a.act = act; a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K;
     a.conv = conv3x3 ? 1 : 0; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
     a.zero = g_zero;
-    int s = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K);
+    int s = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K, conv3x3 ? 1 : 0, conv3x3 ? stride : 0, conv3x3 ? up : 0);
     int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
     if (rc) return rc;
     a.ws = g_ws; a.splitk = s;

@@ -75,16 +75,18 @@ __device__ __forceinline__ void epilogue_store(const Epilogue e, int m, int n, f
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int TN, int CONV, int STAGES>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+template <int TM, int TN, int WM, int WN, int CONV, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XS = TM * 128;          // bytes of one X stage (TM rows x 64 bf16)
     constexpr int WSB = TN * 128;         // bytes of one W stage
     constexpr int STAGE = XS + WSB;
-    constexpr int WP = TN / 32;           // W pieces (1 KiB) per wave
-    constexpr int NI = TN / 32;           // W fragments (16 rows) per wave
-    constexpr int XP = TM / 32;           // X pieces (1 KiB) per wave
-    constexpr int MI = TM / 32;           // X fragments (16 rows) per wave
+    constexpr int NW = WM * WN;           // waves per block (WM along m, WN along n)
+    constexpr int WP = TN / 8 / NW;       // W pieces (1 KiB = 8 rows) per wave
+    constexpr int XP = TM / 8 / NW;       // X pieces per wave
+    constexpr int NI = TN / WN / 16;      // W fragments (16 rows) per wave
+    constexpr int MI = TM / WM / 16;      // X fragments (16 rows) per wave
+    static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8), "tile/wave layout");
     constexpr int LPT = XP + WP;          // global_load_lds per wave per K-tile (exact)
 
     // hoist the argument block into registers (keeps it out of scratch)
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     const int nk_total = (K + BK - 1) / BK;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // ---- per-lane staging geometry -----------------------------------------------------------
     const int lrow = lane >> 3;                               // row inside a 1 KiB piece
-    const int key = (4 * (w & 1) + (lane >> 4)) & 7;          // == ((tile_row >> 1) & 7) for every piece of this wave
+    const int key = (4 * (w & 1) + (lane >> 4)) & 7;          // == ((tile_row >> 1) & 7) for every piece of this wave (NW even)
     const int sc = (lane & 7) ^ key;                          // source 16-B chunk inside the 128-B K row
 
     size_t xoff[XP];                   // LINEAR: element offset of the row;  CONV: pixel-index base of the sample
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int Hup = Hin << up, Wup = Win << up;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-        const int m = m0 + 8 * (w + 4 * i) + lrow;
+        const int m = m0 + 8 * (w + NW * i) + lrow;
         xok[i] = m < M;
         if (CONV) {
             const int hw = Hout * Wout;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     bool wok[WP];
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
-        const int n = n0 + 8 * (w + 4 * i) + lrow;
+        const int n = n0 + 8 * (w + NW * i) + lrow;
         wok[i] = n < N;
         woff[i] = (size_t)n * ldw;
     }
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 ok = kok && xok[i];
                 real = gA + xoff[i] + k;
             }
-            glds16(select_src(real, gZ, ok), xs + (w + 4 * i) * 1024);
+            glds16(select_src(real, gZ, ok), xs + (w + NW * i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < WP; ++i)
-            glds16(select_src(gW + woff[i] + k, gZ, kok && wok[i]), wsm + (w + 4 * i) * 1024);
+            glds16(select_src(gW + woff[i] + k, gZ, kok && wok[i]), wsm + (w + NW * i) * 1024);
     };
 
     f32x4 acc[NI][MI];
@@ -191,12 +193,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             bf16x8 xf[MI], wf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                const int row = wm * (TM / 2) + mi * 16 + frow;
+                const int row = wm * (TM / WM) + mi * 16 + frow;
                 xf[mi] = *(const bf16x8*)(xs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int row = wn * (TN / 2) + ni * 16 + frow;
+                const int row = wn * (TN / WN) + ni * 16 + frow;
                 wf[ni] = *(const bf16x8*)(wsm + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * (TM / 2) + mi * 16 + frow;
+        const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
         if (m >= M) continue;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * (TN / 2) + ni * 16 + 4 * fq;
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
             if (n >= N) continue;
             if (splitk > 1) {
                 *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
@@ -271,25 +273,64 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 
 }  // namespace
 
-struct GemmPlan { int tm, tn, splitk, per; };
+// tile configurations: index -> (TM, TN, waves m x n, stages)
+//   0: 256x128 8 waves (4x2) 3 stages  144 KiB LDS   1 block/CU   85 FLOP per staged byte
+//   1: 128x128 4 waves (2x2) 3 stages   96 KiB        1 block/CU   64
+//   2: 128x128 4 waves (2x2) 2 stages   64 KiB        2 blocks/CU  64
+//   3: 128x64  4 waves (2x2) 3 stages   72 KiB        2 blocks/CU  43
+//   4: 64x128  4 waves (2x2) 3 stages   72 KiB        2 blocks/CU  43
+//   5: 64x64   4 waves (2x2) 4 stages   64 KiB        2 blocks/CU  32
+constexpr int N_TILE_CFG = 6;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64};
 
-// Tile + split-K choice.  Large problems take the 128x128 tile (best FLOP per staged byte); problems that
-// cannot fill the 256 CUs that way step down to 128x64 / 64x64 tiles FIRST (more blocks, no extra traffic)
+struct GemmPlan { int cfg, splitk, per; };
+
+struct TunedEntry { int M, N, K, conv, stride, up, cfg, splitk; };
+static const TunedEntry kTuned[] = {
+#include "gemm_tuned.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
+
+static const TunedEntry* tuned_lookup(int M, int N, int K, int conv, int stride, int up) {
+    for (const TunedEntry* e = kTuned; e->M; ++e)
+        if (e->M == M && e->N == N && e->K == K && e->conv == conv && e->stride == stride && e->up == up) return e;
+    return nullptr;
+}
+
+static int g_force_cfg = -1;     // tuner / tests only
+void gemm_force_tile_cfg(int cfg) { g_force_cfg = (cfg >= 0 && cfg < N_TILE_CFG) ? cfg : -1; }
+
+// Tile + split-K choice.  Large problems take the big tiles (more FLOP per byte staged through L2 -> LDS,
+// which is what bounds these kernels); problems that cannot fill the 256 CUs step down to smaller tiles
 // and only then split K (fp32 partial slabs cost 8 B per output element per slice).
-static GemmPlan gemm_plan(int M, int N, int K, int force_splitk) {
+static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, int stride = 0, int up = 0) {
     const int nk = (K + BK - 1) / BK;
-    const bool n128 = (N % 128 == 0);
-    auto tiles = [&](int tm, int tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
-    GemmPlan g{128, n128 ? 128 : 64, 1, nk};
-    const int want = 224;
-    if (tiles(g.tm, g.tn) < want) {
-        if (tiles(128, 64) >= want || M <= 64) { g.tn = 64; g.tm = (M <= 64 ? 64 : 128); }
-        else { g.tm = 64; g.tn = 64; }
+    auto tiles = [&](int c) { return ((M + kTileM[c] - 1) / kTileM[c]) * ((N + kTileN[c] - 1) / kTileN[c]); };
+    int cfg;
+    const TunedEntry* te = (g_force_cfg < 0 && force_splitk <= 0) ? tuned_lookup(M, N, K, conv, stride, up) : nullptr;
+    if (te) {
+        GemmPlan g;
+        g.cfg = te->cfg;
+        const int s0 = te->splitk < nk ? te->splitk : nk;
+        g.per = (nk + s0 - 1) / s0;
+        g.splitk = (nk + g.per - 1) / g.per;
+        return g;
+    }
+    if (g_force_cfg >= 0) cfg = g_force_cfg;
+    else {
+        const bool n128 = (N % 128 == 0);
+        const int want = 224;
+        if (n128 && tiles(1) >= want) cfg = 1;
+        else if (tiles(3) >= want || (!n128 && M > 64)) cfg = (n128 || tiles(3) >= want) ? 3 : 3;
+        else cfg = 5;
+        if (!n128 && cfg == 1) cfg = 3;
+        if (cfg == 3 && tiles(3) < want && n128) cfg = 5;
+        if (M <= 64) cfg = 5;
     }
     int s = 1;
     if (force_splitk > 0) s = force_splitk;
     else {
-        const int t = tiles(g.tm, g.tn);
+        const int t = tiles(cfg);
         if (t < 160 && nk >= 8) {
             s = (256 + t - 1) / t;
             if (s > nk / 4) s = nk / 4;      // >= 4 K-steps per slice
@@ -298,35 +339,35 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk) {
         }
     }
     if (s > nk) s = nk;
+    GemmPlan g;
+    g.cfg = cfg;
     g.per = (nk + s - 1) / s;
     g.splitk = (nk + g.per - 1) / g.per;
     return g;
 }
 
-int gemm_pick_splitk(int M, int N, int K) { return gemm_plan(M, N, K, 0).splitk; }
-
-// 0: 128x128, 1: 128x64, 3: 64x64 (m x n)
-int gemm_tile_index(int M, int N, int K) {
-    const GemmPlan g = gemm_plan(M, N, K, 0);
-    return (g.tm == 64 ? 2 : 0) + (g.tn == 64 ? 1 : 0);
-}
+int gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).splitk; }
+int gemm_max_splitk() { return 32; }
+int gemm_tile_index(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).cfg; }
 
 size_t gemm_ws_bytes(int M, int N, int splitk) {
     return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
 }
 
-template <int TM, int TN, int STAGES>
-static int launch_tile(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+template <int TM, int TN, int WM, int WN, int STAGES>
+static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
     const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128);
     static bool attr_set[2] = {false, false};
     if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
-        hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                              : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, 0, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                              : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
         attr_set[a.conv ? 1 : 0] = true;
     }
-    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, 1, STAGES>), grid, dim3(256), lds, stream, a);
-    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, 0, STAGES>), grid, dim3(256), lds, stream, a);
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 block(64 * WM * WN);
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, a);
     return 0;
 }
 
@@ -339,15 +380,19 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (!a.out_f32 && (a.ldc % 4)) return mkd_fail(-1, "gemm: ldc must be a multiple of 4");
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
-    const GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk);
+    const GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
     if (g.splitk > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
     a.splitk = g.splitk;
     a.ksteps_per_split = g.per;
-    dim3 grid((a.M + g.tm - 1) / g.tm, (a.N + g.tn - 1) / g.tn, g.splitk);
     int rc;
-    if (g.tm == 128 && g.tn == 128) rc = launch_tile<128, 128, 3>(a, grid, stream);      // 96 KiB LDS, 1 block/CU
-    else if (g.tm == 128 && g.tn == 64) rc = launch_tile<128, 64, 3>(a, grid, stream);   // 72 KiB, 2 blocks/CU
-    else rc = launch_tile<64, 64, 4>(a, grid, stream);                                    // 64 KiB, 2 blocks/CU
+    switch (g.cfg) {
+        case 0: rc = launch_tile<256, 128, 4, 2, 3>(a, g.splitk, stream); break;
+        case 1: rc = launch_tile<128, 128, 2, 2, 3>(a, g.splitk, stream); break;
+        case 2: rc = launch_tile<128, 128, 2, 2, 2>(a, g.splitk, stream); break;
+        case 3: rc = launch_tile<128, 64, 2, 2, 3>(a, g.splitk, stream); break;
+        case 4: rc = launch_tile<64, 128, 2, 2, 3>(a, g.splitk, stream); break;
+        default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
+    }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("gemm_kernel");
     if (g.splitk > 1) {

@@ -65,8 +65,9 @@ struct GemmArgs {
 
 // launchers (each only enqueues on `stream`)
 int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
-int  gemm_pick_splitk(int M, int N, int K);
-int  gemm_tile_index(int M, int N, int K);   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
+int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
+int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
+void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
 size_t gemm_ws_bytes(int M, int N, int splitk);
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,

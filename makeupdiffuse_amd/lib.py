@@ -55,6 +55,7 @@ SIGNATURES = {
     'mkd_device_bytes': (_L, [_P]),
     'mkd_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'mkd_gemm_force_tile': (_I, [_I]),
     'mkd_groupnorm': (_I, [_P, _I, _P, _P, _F, _I, _P, _I, _I, _I, _I, _I, _P]),
     'mkd_layernorm': (_I, [_P, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
