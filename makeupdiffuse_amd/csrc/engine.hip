@@ -67,6 +67,15 @@ struct Epi {
 
 typedef std::function<int(hipStream_t)> OpFn;
 
+struct Op {
+    OpFn fn;
+    int kind = 0;
+    double flops = 0;
+    int launches = 0;
+    std::string label;
+    int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
+};
+
 enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 6, K_GROUPNORM = 12, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_256x128", "gemm_conv3x3_128x128_s3", "gemm_conv3x3_128x128_s2", "gemm_conv3x3_128x64",
                                          "gemm_conv3x3_64x128", "gemm_conv3x3_64x64",
@@ -99,14 +108,17 @@ struct mkd_ctx {
     bool has_control = false, only_mid = false;
     float scales[64];
     int n_ctrl() const { return (int)encoder_spec().size() + 1; }
-    Arena persist, temp;
-    char* persist_base = nullptr; char* temp_base = nullptr;
-    size_t persist_cap = 0, temp_cap = 0;
-    float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0, splitk_need = 0;
-    float* gn_ws = nullptr; size_t gn_ws_bytes = 0, gn_need = 0;
-    std::vector<OpFn> plan_prepare, plan_eps;
+    Arena persist, temp_arena[2];
+    int cur_sid = 0;
+    Arena& TA() { return temp_arena[cur_sid]; }
+    char* persist_base = nullptr; char* temp_base[2] = {nullptr, nullptr};
+    size_t persist_cap = 0, temp_cap[2] = {0, 0};
+    float* splitk_ws[2] = {nullptr, nullptr}; size_t splitk_ws_bytes[2] = {0, 0}, splitk_need = 0;
+    float* gn_ws[2] = {nullptr, nullptr}; size_t gn_ws_bytes[2] = {0, 0}, gn_need = 0;
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
+    std::vector<Op> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
-    std::vector<int> kind_eps; std::vector<double> opflops_eps; std::vector<int> oplaunch_eps; std::vector<std::string> label_eps;
     bool dry = false; bool counting_eps = false;
     std::map<std::string, Tensor> kv_cache;       // transformer prefix -> [B*77, 2d]
     Tensor hint_emb;
@@ -378,14 +390,14 @@ struct mkd_ctx {
     }
 
     // ---- plan building ------------------------------------------------------------------------------
-    void push(std::vector<OpFn>& plan, OpFn f, int launches, double flops, int kind = K_MISC, const std::string& label = "") {
+    void push(std::vector<Op>& plan, OpFn f, int launches, double flops, int kind = K_MISC, const std::string& label = "") {
         if (counting_eps) { launches_eps += launches; flops_eps += flops; }
         if (!dry) {
-            plan.push_back(std::move(f));
-            if (counting_eps) { kind_eps.push_back(kind); opflops_eps.push_back(flops); oplaunch_eps.push_back(launches); label_eps.push_back(label); }
+            Op o; o.fn = std::move(f); o.kind = kind; o.flops = flops; o.launches = launches; o.label = label; o.sid = cur_sid;
+            plan.push_back(std::move(o));
         }
     }
-    std::vector<OpFn>* cur_plan = nullptr;
+    std::vector<Op>* cur_plan = nullptr;
 
     Tensor talloc(Arena& a, int B_, int H_, int W_, int C_) {
         Tensor t; t.B = B_; t.H = H_; t.W = W_; t.C = C_; t.ld = C_;
@@ -400,7 +412,8 @@ struct mkd_ctx {
         const size_t need = gemm_ws_bytes(a.M, a.N, s);
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
-        push(*cur_plan, [self, a](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws; return launch_gemm(b, st); },
+        const int sid = cur_sid;
+        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[sid]; return launch_gemm(b, st); },
              s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
              (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0),
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
@@ -431,8 +444,9 @@ struct mkd_ctx {
         if (need > gn_need) gn_need = need;
         mkd_ctx* self = this;
         Tensor t = in;
-        push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out](hipStream_t st) {
-            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws, st);
+        const int sid = cur_sid;
+        push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out, sid](hipStream_t st) {
+            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[sid], st);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
@@ -455,18 +469,18 @@ struct mkd_ctx {
 
     // ResBlock (App. A.2).  x may be a concat buffer (ld == C).  Writes [rows, cout] at (out, ldo).
     void resblock(const std::string& p, const Tensor& x, int cout, const float* embproj, int ld_emb, bf16_t* out, int ldo) {
-        const size_t mk = temp.mark();
+        const size_t mk = TA().mark();
         const int rows = x.rows(), hw = x.H * x.W;
-        Tensor t1 = talloc(temp, x.B, x.H, x.W, x.C);
+        Tensor t1 = talloc(TA(), x.B, x.H, x.W, x.C);
         op_gn(x, wf(p + ".in_layers.0.weight"), wf(p + ".in_layers.0.bias"), 1e-5f, 1, t1.p, t1.ld);
-        Tensor t2 = talloc(temp, x.B, x.H, x.W, cout);
+        Tensor t2 = talloc(TA(), x.B, x.H, x.W, cout);
         Epi e1; e1.bias = wf(p + ".in_layers.2.bias"); e1.rowbias = embproj + emb_off.at(p); e1.ldrb = ld_emb; e1.rpb = hw;
         op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
-        Tensor t3 = talloc(temp, x.B, x.H, x.W, cout);
+        Tensor t3 = talloc(TA(), x.B, x.H, x.W, cout);
         op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
         Epi e2; e2.bias = wf(p + ".out_layers.3.bias");
         if (x.C != cout) {
-            Tensor t4 = talloc(temp, x.B, x.H, x.W, cout);
+            Tensor t4 = talloc(TA(), x.B, x.H, x.W, cout);
             Epi es; es.bias = wf(p + ".skip_connection.bias");
             op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
             e2.R = t4.p; e2.ldr = t4.ld;
@@ -474,15 +488,15 @@ struct mkd_ctx {
             e2.R = x.p; e2.ldr = x.ld;
         }
         op_conv(t3, wb(p + ".out_layers.3.weight"), cout, 1, 0, e2, out, ldo);
-        temp.release(mk);
+        TA().release(mk);
     }
 
     // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
     void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo) {
-        const size_t mk = temp.mark();
+        const size_t mk = TA().mark();
         const int d = x.C, M = x.rows(), T = x.H * x.W, heads = cfg.num_heads, dh = d / heads;
         const std::string t = p + ".transformer_blocks.0";
-        auto buf = [&](int cols) { return (bf16_t*)temp.alloc((size_t)M * cols * sizeof(bf16_t)); };
+        auto buf = [&](int cols) { return (bf16_t*)TA().alloc((size_t)M * cols * sizeof(bf16_t)); };
         bf16_t* g = buf(d);
         op_gn(x, wf(p + ".norm.weight"), wf(p + ".norm.bias"), 1e-6f, 0, g, d);
         bf16_t* h0 = buf(d);
@@ -520,7 +534,7 @@ struct mkd_ctx {
           op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
         { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld;
           op_linear(h3, d, M, d, wb(p + ".proj_out.weight"), d, e, out, ldo); }
-        temp.release(mk);
+        TA().release(mk);
     }
 
     // time embedding MLP + every ResBlock's emb projection in one GEMM -> fp32 [B, emb_total]
@@ -563,11 +577,11 @@ struct mkd_ctx {
             } else if (b.kind == 1) {
                 Tensor o = talloc(persist, hcur.B, hcur.H, hcur.W, b.cout);
                 if (b.attn) {
-                    const size_t mk = temp.mark();
-                    Tensor r = talloc(temp, hcur.B, hcur.H, hcur.W, b.cout);
+                    const size_t mk = TA().mark();
+                    Tensor r = talloc(TA(), hcur.B, hcur.H, hcur.W, b.cout);
                     resblock(p + ".0", hcur, b.cout, embproj, ld_emb, r.p, r.ld);
                     spatial_transformer(p + ".1", r, o.p, o.ld);
-                    temp.release(mk);
+                    TA().release(mk);
                 } else {
                     resblock(p + ".0", hcur, b.cout, embproj, ld_emb, o.p, o.ld);
                 }
@@ -581,14 +595,14 @@ struct mkd_ctx {
             feats.push_back(hcur);
         }
         const int ch = hcur.C;
-        const size_t mk = temp.mark();
-        Tensor m1 = talloc(temp, hcur.B, hcur.H, hcur.W, ch);
+        const size_t mk = TA().mark();
+        Tensor m1 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
         resblock(P + "middle_block.0", hcur, ch, embproj, ld_emb, m1.p, m1.ld);
-        Tensor m2 = talloc(temp, hcur.B, hcur.H, hcur.W, ch);
+        Tensor m2 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
         spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld);
         Tensor m3 = talloc(persist, hcur.B, hcur.H, hcur.W, ch);
         resblock(P + "middle_block.2", m2, ch, embproj, ld_emb, m3.p, m3.ld);
-        temp.release(mk);
+        TA().release(mk);
         return m3;
     }
 
@@ -622,8 +636,8 @@ struct mkd_ctx {
             for (int j = 0; j < 7; ++j) widths[j + 1] = cfg.hint_widths[j];
             widths[8] = cfg.model_channels;
             const int H0 = 8 * h, W0 = 8 * w;
-            const size_t mk = temp.mark();
-            Tensor cur = talloc(temp, B, H0, W0, widths[1]);
+            const size_t mk = TA().mark();
+            Tensor cur = talloc(TA(), B, H0, W0, widths[1]);
             {
                 const bf16_t* wgt = wb(P + "input_hint_block.0.weight"); const float* bias = wf(P + "input_hint_block.0.bias");
                 const int Bn = B, cin = widths[0], cout = widths[1];
@@ -634,29 +648,54 @@ struct mkd_ctx {
             for (int j = 1; j < 8; ++j) {
                 const int s = strides[j];
                 const int Ho = (cur.H - 1) / s + 1, Wo = (cur.W - 1) / s + 1;
-                Tensor nxt = (j == 7) ? talloc(persist, B, Ho, Wo, widths[j + 1]) : talloc(temp, B, Ho, Wo, widths[j + 1]);
+                Tensor nxt = (j == 7) ? talloc(persist, B, Ho, Wo, widths[j + 1]) : talloc(TA(), B, Ho, Wo, widths[j + 1]);
                 Epi e; e.bias = wf(P + "input_hint_block." + std::to_string(2 * j) + ".bias"); e.act = (j == 7) ? 0 : 1;
                 op_conv(cur, wb(P + "input_hint_block." + std::to_string(2 * j) + ".weight"), widths[j + 1], s, 0, e, nxt.p, nxt.ld);
                 cur = nxt;
             }
             hint_emb = cur;
-            temp.release(mk);
+            TA().release(mk);
         }
     }
 
     void build_eps_plan() {
         cur_plan = &plan_eps;
         counting_eps = true;
-        flops_eps = 0; launches_eps = 0; kind_eps.clear(); opflops_eps.clear(); oplaunch_eps.clear(); label_eps.clear();
+        flops_eps = 0; launches_eps = 0;
         mkd_ctx* self = this;
         std::vector<Tensor> cn_feats, hs;
         Tensor cn_mid, u_mid;
+        // The ControlNet and the UNet encoder+middle only meet at the zero-conv "combine": build them as two
+        // op lists, run the ControlNet on the side stream and interleave the enqueue order so both streams
+        // are fed from the first launch on.
+        std::vector<Op> ops_cn, ops_ue;
+        float* ep0 = nullptr;
         if (has_control) {
+            cur_plan = &ops_cn; cur_sid = 1;
             float* ep = time_embedding(1);
             cn_mid = encoder(1, ep, cn_feats);
         }
-        float* ep0 = time_embedding(0);
+        cur_plan = &ops_ue; cur_sid = 0;
+        ep0 = time_embedding(0);
         u_mid = encoder(0, ep0, hs);
+        cur_plan = &plan_eps; cur_sid = 0;
+        if (!dry) {
+            if (has_control) {
+                Op f; f.kind = K_MISC; f.label = "fork";
+                f.fn = [self](hipStream_t) { return self->fork_side(); };
+                plan_eps.push_back(std::move(f));
+            }
+            size_t a = 0, b2 = 0;
+            while (a < ops_cn.size() || b2 < ops_ue.size()) {
+                if (a < ops_cn.size()) plan_eps.push_back(std::move(ops_cn[a++]));
+                if (b2 < ops_ue.size()) plan_eps.push_back(std::move(ops_ue[b2++]));
+            }
+            if (has_control) {
+                Op j; j.kind = K_MISC; j.label = "join";
+                j.fn = [self](hipStream_t) { return self->join_side(); };
+                plan_eps.push_back(std::move(j));
+            }
+        }
 
         auto dec = decoder_spec();
         const std::string P = net_prefix(0), PC = net_prefix(1);
@@ -696,7 +735,7 @@ struct mkd_ctx {
                 nxt_cat = talloc(persist, cat.B, outH, outW, b.cout);
                 dst = nxt_cat.p; dst_ld = nxt_cat.ld;
             }
-            const size_t mk = temp.mark();
+            const size_t mk = TA().mark();
             const int stages = 1 + (b.attn ? 1 : 0) + (b.up ? 1 : 0);
             Tensor cur_in = cat;
             int stage = 0;
@@ -705,7 +744,7 @@ struct mkd_ctx {
                 ++stage;
                 Tensor o; bf16_t* op_; int ol;
                 if (stage == stages) { op_ = dst; ol = dst_ld; o.p = dst; }
-                else { o = talloc(temp, cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
+                else { o = talloc(TA(), cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
                 resblock(p + ".0", cur_in, b.cout, ep0, emb_total[0], op_, ol);
                 cur_in.p = op_; cur_in.C = b.cout; cur_in.ld = ol;
             }
@@ -713,7 +752,7 @@ struct mkd_ctx {
                 ++stage;
                 bf16_t* op_; int ol;
                 if (stage == stages) { op_ = dst; ol = dst_ld; }
-                else { Tensor o = talloc(temp, cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
+                else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
                 spatial_transformer(p + ".1", cur_in, op_, ol);
                 cur_in.p = op_; cur_in.ld = ol;
             }
@@ -722,20 +761,20 @@ struct mkd_ctx {
                 Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias");
                 op_conv(cur_in, wb(p + "." + std::to_string(k) + ".conv.weight"), b.cout, 1, 1, e, dst, dst_ld);
             }
-            temp.release(mk);
+            TA().release(mk);
             cat = nxt_cat;
         }
         // out: GN32 + SiLU + conv3x3 C -> out_channels (fp32 NCHW)
         {
-            const size_t mk = temp.mark();
-            Tensor g = talloc(temp, cat.B, cat.H, cat.W, cat.C);
+            const size_t mk = TA().mark();
+            Tensor g = talloc(TA(), cat.B, cat.H, cat.W, cat.C);
             op_gn(cat, wf(P + "out.0.weight"), wf(P + "out.0.bias"), 1e-5f, 1, g.p, g.ld);
             const bf16_t* wgt = wb(P + "out.2.weight"); const float* bias = wf(P + "out.2.bias");
             const int Bn = B, hh = h, ww = w, cin = cat.C, cout = cfg.out_channels;
             push(*cur_plan, [self, g, wgt, bias, Bn, hh, ww, cin, cout](hipStream_t st) {
                 return launch_conv3x3_direct(g.p, 0, wgt, bias, self->io_out, 1, 0, nullptr, Bn, hh, ww, cin, cout, 1, st);
             }, 1, 2.0 * B * h * w * cfg.out_channels * 9 * cat.C, K_CONV_DIRECT);
-            temp.release(mk);
+            TA().release(mk);
         }
         counting_eps = false;
     }
@@ -765,18 +804,28 @@ struct mkd_ctx {
             prepared = false;
             // pass 1: dry run to size the arenas (pointers are offsets from null and never dereferenced)
             dry = true;
-            persist.base = nullptr; temp.base = nullptr; persist.reset(); temp.reset();
+            persist.base = nullptr; persist.reset();
+            for (int i = 0; i < 2; ++i) { temp_arena[i].base = nullptr; temp_arena[i].reset(); }
             splitk_need = 0; gn_need = 0;
             plan_prepare.clear(); plan_eps.clear();
+            cur_sid = 0;
             build_prepare_plan(); build_eps_plan();
-            const size_t pneed = persist.high + 256, tneed = temp.high + 256;
-            int rc = ensure((void**)&persist_base, &persist_cap, pneed); if (rc) return rc;
-            rc = ensure((void**)&temp_base, &temp_cap, tneed); if (rc) return rc;
-            rc = ensure((void**)&splitk_ws, &splitk_ws_bytes, splitk_need); if (rc) return rc;
-            rc = ensure((void**)&gn_ws, &gn_ws_bytes, gn_need); if (rc) return rc;
+            int rc = ensure((void**)&persist_base, &persist_cap, persist.high + 256); if (rc) return rc;
+            for (int i = 0; i < 2; ++i) {
+                rc = ensure((void**)&temp_base[i], &temp_cap[i], temp_arena[i].high + 256); if (rc) return rc;
+                rc = ensure((void**)&splitk_ws[i], &splitk_ws_bytes[i], splitk_need); if (rc) return rc;
+                rc = ensure((void**)&gn_ws[i], &gn_ws_bytes[i], gn_need); if (rc) return rc;
+            }
+            if (!side_stream) {
+                MKD_HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            }
             // pass 2: real plan
             dry = false;
-            persist.base = persist_base; temp.base = temp_base; persist.reset(); temp.reset();
+            persist.base = persist_base; persist.reset();
+            for (int i = 0; i < 2; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
+            cur_sid = 0;
             build_prepare_plan(); build_eps_plan();
             // sampler buffers
             const size_t lat = (size_t)B * cfg.in_channels * h * w * sizeof(float);
@@ -787,7 +836,7 @@ struct mkd_ctx {
             if (s_t) { hipFree(s_t); s_t = nullptr; }
             MKD_HIP_CHECK(hipMalloc((void**)&s_t, (size_t)B * sizeof(int64_t)));
         }
-        for (auto& f : plan_prepare) { int rc = f(stream); if (rc) return rc; }
+        for (auto& op : plan_prepare) { int rc = op.fn(stream); if (rc) return rc; }
         prepared = true;
         return 0;
     }
@@ -796,7 +845,25 @@ struct mkd_ctx {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps before mkd_prepare");
         if (!x || !t || !out) return mkd_fail(MKD_ERR_ARG, "mkd_eps: null pointer");
         io_x = x; io_t = t; io_out = out;
-        for (auto& f : plan_eps) { int rc = f(stream); if (rc) return rc; }
+        run_main = stream; run_serial = !dual_stream;
+        for (auto& op : plan_eps) {
+            int rc = op.fn((op.sid == 1 && !run_serial) ? side_stream : stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+
+    // side stream starts after everything already enqueued on the caller's stream (x, t, previous eval)
+    int fork_side() {
+        if (run_serial) return 0;
+        MKD_HIP_CHECK(hipEventRecord(ev_fork, run_main));
+        MKD_HIP_CHECK(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        return 0;
+    }
+    int join_side() {
+        if (run_serial) return 0;
+        MKD_HIP_CHECK(hipEventRecord(ev_join, side_stream));
+        MKD_HIP_CHECK(hipStreamWaitEvent(run_main, ev_join, 0));
         return 0;
     }
 
@@ -805,13 +872,14 @@ struct mkd_ctx {
                     const char* csv_path = nullptr) {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps_profile before mkd_prepare");
         io_x = x; io_t = t; io_out = out;
+        run_main = stream; run_serial = true;          // profile on ONE stream: per-launch times are not overlapped
         const size_t n = plan_eps.size();
         std::vector<hipEvent_t> ev(n + 1);
         for (auto& e : ev) MKD_HIP_CHECK(hipEventCreate(&e));
         int rc = 0;
         MKD_HIP_CHECK(hipEventRecord(ev[0], stream));
         for (size_t i = 0; i < n && !rc; ++i) {
-            rc = plan_eps[i](stream);
+            rc = plan_eps[i].fn(stream);
             if (!rc && hipEventRecord(ev[i + 1], stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipEventRecord");
         }
         if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipStreamSynchronize");
@@ -821,8 +889,9 @@ struct mkd_ctx {
         for (size_t i = 0; i < n && !rc; ++i) {
             float dt = 0.f;
             if (hipEventElapsedTime(&dt, ev[i], ev[i + 1]) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime"); break; }
-            ms[kind_eps[i]] += dt; flops[kind_eps[i]] += opflops_eps[i]; launches[kind_eps[i]] += oplaunch_eps[i];
-            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kKindNames[kind_eps[i]], label_eps[i].c_str(), dt, opflops_eps[i] / 1e9);
+            const Op& op = plan_eps[i];
+            ms[op.kind] += dt; flops[op.kind] += op.flops; launches[op.kind] += op.launches;
+            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kKindNames[op.kind], op.label.c_str(), dt, op.flops / 1e9);
         }
         if (csv) fclose(csv);
         for (auto& e : ev) hipEventDestroy(e);
@@ -863,12 +932,14 @@ struct mkd_ctx {
     }
 
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)persist_cap + (int64_t)temp_cap + (int64_t)splitk_ws_bytes + (int64_t)gn_ws_bytes;
+        return weight_bytes + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
+               (int64_t)(gn_ws_bytes[0] + gn_ws_bytes[1]);
     }
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
-        for (void* p : {(void*)persist_base, (void*)temp_base, (void*)splitk_ws, (void*)gn_ws, (void*)s_xa, (void*)s_xb,
+        if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
+        for (void* p : {(void*)persist_base, (void*)temp_base[0], (void*)temp_base[1], (void*)splitk_ws[0], (void*)splitk_ws[1], (void*)gn_ws[0], (void*)gn_ws[1], (void*)s_xa, (void*)s_xb,
                         (void*)s_xin, (void*)s_eps, (void*)s_t})
             if (p) hipFree(p);
     }
