@@ -129,6 +129,9 @@ struct mkd_ctx {
     // sampler buffers
     float* s_xa = nullptr; float* s_xb = nullptr; float* s_xin = nullptr; float* s_eps = nullptr;
     int64_t* s_t = nullptr;
+    StepState* s_state = nullptr; StepState* h_state = nullptr;
+    hipStream_t loop_stream = nullptr; hipEvent_t ev_loop_in = nullptr, ev_loop_out = nullptr;
+    hipGraphExec_t step_graph = nullptr; int step_graph_cfg = -1; float step_graph_scale = 0.f; int plan_generation = 0, step_graph_gen = -1;
 
     // ---------------------------------------------------------------------------------------------
     int ctx_len() const { return 77; }
@@ -827,6 +830,7 @@ struct mkd_ctx {
             for (int i = 0; i < 2; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
             cur_sid = 0;
             build_prepare_plan(); build_eps_plan();
+            ++plan_generation; drop_graph();
             // sampler buffers
             const size_t lat = (size_t)B * cfg.in_channels * h * w * sizeof(float);
             for (float** q : {&s_xa, &s_xb, &s_xin, &s_eps}) {
@@ -898,9 +902,29 @@ struct mkd_ctx {
         return rc;
     }
 
+    void drop_graph() {
+        if (step_graph) { hipGraphExecDestroy(step_graph); step_graph = nullptr; }
+        step_graph_gen = -1;
+    }
+
+    // enqueue ONE reverse step that reads its timestep / coefficients from the device step state (graph body)
+    int enqueue_state_step(int batch, bool cfg_on, float cfg_scale, hipStream_t stream) {
+        const int64_t n = (int64_t)batch * cfg.in_channels * h * w;
+        int rc = launch_step_setup(s_state, s_t, B, stream); if (rc) return rc;
+        const float* ec; const float* eu = nullptr;
+        if (cfg_on) {
+            rc = launch_repeat_batch(s_xa, s_xin, n, 2, stream); if (rc) return rc;
+            rc = eps(s_xin, s_t, s_eps, stream); if (rc) return rc;
+            eu = s_eps; ec = s_eps + n;
+        } else {
+            rc = eps(s_xa, s_t, s_eps, stream); if (rc) return rc;
+            ec = s_eps;
+        }
+        return launch_ddim_step_state(s_xa, ec, eu, cfg_scale, s_state, n, stream);
+    }
+
     int sample(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
                const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
-        (void)use_graph;
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_sample before mkd_prepare");
         const bool cfg_on = cfg_scale != 1.0f;
         if (cfg_on ? (B != 2 * batch) : (B != batch))
@@ -909,6 +933,49 @@ struct mkd_ctx {
             return mkd_fail(MKD_ERR_ARG, "mkd_sample: bad arguments");
         const int64_t n = (int64_t)batch * cfg.in_channels * h * w;
         MKD_HIP_CHECK(hipMemcpyAsync(s_xa, x_T, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        if (use_graph) {
+            // --- hipGraph path: one captured step (both streams, fork/join included), replayed n_steps times ---
+            if (n_steps > MKD_MAX_STEPS) return mkd_fail(MKD_ERR_ARG, "mkd_sample: too many steps for the graph path");
+            if (!h_state) MKD_HIP_CHECK(hipHostMalloc((void**)&h_state, sizeof(StepState)));
+            if (!s_state) MKD_HIP_CHECK(hipMalloc((void**)&s_state, sizeof(StepState)));
+            if (!loop_stream) {
+                // the caller's stream may be the legacy null stream, which cannot be captured: run the loop on a
+                // private stream ordered against the caller's with events
+                MKD_HIP_CHECK(hipStreamCreateWithFlags(&loop_stream, hipStreamNonBlocking));
+                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_loop_in, hipEventDisableTiming));
+                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_loop_out, hipEventDisableTiming));
+            }
+            MKD_HIP_CHECK(hipStreamSynchronize(loop_stream));     // h_state may still feed a previous call's copy
+            h_state->counter = n_steps - 1;
+            for (int i = 0; i < n_steps; ++i) {
+                h_state->timesteps[i] = timesteps[i];
+                h_state->coef[4 * i + 0] = 1.0f / sqrtf(alphas[i]);
+                h_state->coef[4 * i + 1] = sqrtf(alphas_prev[i]);
+                h_state->coef[4 * i + 2] = sqrtf(1.0f - alphas_prev[i]);
+                h_state->coef[4 * i + 3] = s1m[i];
+            }
+            MKD_HIP_CHECK(hipEventRecord(ev_loop_in, stream));
+            MKD_HIP_CHECK(hipStreamWaitEvent(loop_stream, ev_loop_in, 0));
+            MKD_HIP_CHECK(hipMemcpyAsync(s_state, h_state, sizeof(StepState), hipMemcpyHostToDevice, loop_stream));
+            if (!step_graph || step_graph_gen != plan_generation || step_graph_cfg != (int)cfg_on || step_graph_scale != cfg_scale) {
+                drop_graph();
+                hipGraph_t g = nullptr;
+                MKD_HIP_CHECK(hipStreamBeginCapture(loop_stream, hipStreamCaptureModeRelaxed));
+                int rc = enqueue_state_step(batch, cfg_on, cfg_scale, loop_stream);
+                hipError_t e = hipStreamEndCapture(loop_stream, &g);
+                if (rc) { if (g) hipGraphDestroy(g); return rc; }
+                if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                e = hipGraphInstantiate(&step_graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (e != hipSuccess) { step_graph = nullptr; return mkd_fail(MKD_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+                step_graph_gen = plan_generation; step_graph_cfg = (int)cfg_on; step_graph_scale = cfg_scale;
+            }
+            for (int i = 0; i < n_steps; ++i) MKD_HIP_CHECK(hipGraphLaunch(step_graph, loop_stream));
+            MKD_HIP_CHECK(hipMemcpyAsync(x_out, s_xa, n * sizeof(float), hipMemcpyDeviceToDevice, loop_stream));
+            MKD_HIP_CHECK(hipEventRecord(ev_loop_out, loop_stream));
+            MKD_HIP_CHECK(hipStreamWaitEvent(stream, ev_loop_out, 0));
+            return 0;
+        }
         float* xa = s_xa; float* xb = s_xb;
         for (int i = 0; i < n_steps; ++i) {
             const int index = n_steps - 1 - i;
@@ -938,6 +1005,10 @@ struct mkd_ctx {
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
+        drop_graph();
+        if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
+        if (h_state) hipHostFree(h_state);
+        if (s_state) hipFree(s_state);
         if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
         for (void* p : {(void*)persist_base, (void*)temp_base[0], (void*)temp_base[1], (void*)splitk_ws[0], (void*)splitk_ws[1], (void*)gn_ws[0], (void*)gn_ws[1], (void*)s_xa, (void*)s_xb,
                         (void*)s_xin, (void*)s_eps, (void*)s_t})

@@ -25,6 +25,34 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// ---- device-resident step state for hipGraph replay of the DDIM loop -------------------------------------
+// One graph = one reverse step; what changes between steps (timestep, schedule coefficients) is read from
+// device tables through a counter that the first kernel of the graph advances, so the SAME graph replays.
+__global__ void step_setup_kernel(StepState* st, int64_t* t_out, int batch) {
+    __shared__ int idx;
+    if (threadIdx.x == 0) idx = st->counter;
+    __syncthreads();
+    const int i = idx;
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) t_out[b] = st->timesteps[i];
+    if (threadIdx.x == 0) {
+        st->cur[0] = st->coef[4 * i + 0]; st->cur[1] = st->coef[4 * i + 1];
+        st->cur[2] = st->coef[4 * i + 2]; st->cur[3] = st->coef[4 * i + 3];
+        st->counter = i - 1;
+    }
+}
+
+// in-place x <- x_{t-1} (eta == 0), coefficients from the step state
+__global__ void ddim_step_state_kernel(float* __restrict__ x, const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                       float cfg_scale, const StepState* __restrict__ st, int64_t n) {
+    const float sqrt_at_inv = st->cur[0], sqrt_aprev = st->cur[1], dir_coef = st->cur[2], s1m = st->cur[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e = eps_c[i];
+        if (eps_u) { const float u = eps_u[i]; e = u + cfg_scale * (e - u); }
+        const float p0 = (x[i] - s1m * e) * sqrt_at_inv;
+        x[i] = sqrt_aprev * p0 + dir_coef * e;
+    }
+}
+
 // ---- GEGLU: y = a * gelu_erf(gate) ----------------------------------------------------------------
 __global__ void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int rows, int inner) {
     const int vper = inner >> 3;
@@ -90,6 +118,54 @@ __global__ void conv3x3_direct_kernel(const void* __restrict__ xin, int in_nchw_
         if (add) acc += bf16_to_f32(add[opix * Cout + co]);
         if (out_nchw_f32) ((float*)yout)[(((size_t)b * Cout + co) * Hout + oy) * Wout + ox] = acc;
         else ((bf16_t*)yout)[opix * Cout + co] = f32_to_bf16(acc);
+    }
+}
+
+// ---- 3x3 conv with a tiny Cin read from fp32 NCHW (the 4 -> 320 input conv): thread = output channel, the
+// thread's 9*CIN weights live in registers, a block walks pixels with the 9*CIN input patch shared through LDS.
+template <int CIN>
+__global__ __launch_bounds__(512) void conv3x3_fewin_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                            const bf16_t* __restrict__ add, int act, int batch, int H, int W,
+                                                            int Cout, int pix_per_block) {
+    constexpr int KK = 9 * CIN;
+    __shared__ float patch[2][KK];
+    const int co = threadIdx.x;
+    const bool live = co < Cout;
+    float wr[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) wr[k] = live ? bf16_to_f32(w[(size_t)co * KK + k]) : 0.f;
+    const float bz = (live && bias) ? bias[co] : 0.f;
+    const int npix = batch * H * W;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(npix, p0 + pix_per_block);
+    auto load_patch = [&](int pix, int slot) {
+        if (threadIdx.x < KK) {
+            const int tap = threadIdx.x / CIN, ci = threadIdx.x - tap * CIN;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int b = pix / (H * W);
+            const int rem = pix - b * H * W;
+            const int oy = rem / W, ox = rem - oy * W;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((size_t)b * CIN + ci) * H + iy) * W + ix];
+            patch[slot][threadIdx.x] = v;
+        }
+    };
+    if (p0 < p1) load_patch(p0, 0);
+    __syncthreads();
+    for (int pix = p0; pix < p1; ++pix) {
+        const int slot = (pix - p0) & 1;
+        if (pix + 1 < p1) load_patch(pix + 1, slot ^ 1);
+        float acc = bz;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc += patch[slot][k] * wr[k];
+        if (live) {
+            if (act == 1) acc = silu_f(acc);
+            if (add) acc += bf16_to_f32(add[(size_t)pix * Cout + co]);
+            y[(size_t)pix * Cout + co] = f32_to_bf16(acc);
+        }
+        __syncthreads();
     }
 }
 
@@ -216,6 +292,15 @@ int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
                           int Cin, int Cout, int stride, hipStream_t stream) {
     if (stride != 1 && stride != 2) return mkd_fail(-1, "conv3x3_direct: stride must be 1 or 2");
+    if (in_nchw_f32 && !out_nchw_f32 && stride == 1 && Cin == 4 && Cout >= 64 && Cout <= 512) {
+        const int npix = batch * Hin * Win;
+        const int ppb = 8;
+        const int threads = (Cout + 63) / 64 * 64;
+        hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, dim3((npix + ppb - 1) / ppb), dim3(threads), 0, stream, (const float*)x, w, bias,
+                           (bf16_t*)y, add, act, batch, Hin, Win, Cout, ppb);
+        MKD_LAUNCH_CHECK("conv3x3_fewin_kernel");
+        return 0;
+    }
     if (!in_nchw_f32 && out_nchw_f32 && Cout == 4 && stride == 1 && act == 0 && !add && Cin % 8 == 0) {
         const int npix = batch * Hin * Win;
         hipLaunchKernelGGL(conv3x3_fewout_kernel<4>, dim3((npix + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
@@ -261,5 +346,18 @@ int launch_repeat_batch(const float* x, float* y, int64_t n_per, int reps, hipSt
 int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream) {
     hipLaunchKernelGGL(fill_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
     MKD_LAUNCH_CHECK("fill_i64_kernel");
+    return 0;
+}
+
+int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream) {
+    hipLaunchKernelGGL(step_setup_kernel, dim3(1), dim3(64), 0, stream, st, t_out, batch);
+    MKD_LAUNCH_CHECK("step_setup_kernel");
+    return 0;
+}
+
+int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, const StepState* st, int64_t n,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(ddim_step_state_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, cfg_scale, st, n);
+    MKD_LAUNCH_CHECK("ddim_step_state_kernel");
     return 0;
 }

@@ -119,7 +119,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t*
 // Single-launch GroupNorm for slabs that stay cache-resident: one workgroup per (sample, chunk of `gpb`
 // groups whose channel span is a multiple of 8).  Pass 1 accumulates per-channel sums in registers, a
 // deterministic 3-stage LDS reduction folds them per group, pass 2 re-reads the slab (L2 hit) and applies.
-__global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
                                                        int ld_out, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu, int hw,
                                                        int C, int groups, int gpb) {
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
     const int cg = C / groups;
     const int nch = gpb * cg;                 // channels of this block (multiple of 8)
     const int V = nch >> 3;
-    const int P = 256 / V;
+    const int NT = blockDim.x;
+    const int P = NT / V;
     const int T = V * P;                      // active threads
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
         }
     }
     float* ssum = s_red;                      // [T][8]
-    float* ssq = s_red + 256 * 8;             // [T][8]
-    float* csum = s_red + 2 * 256 * 8;        // [nch] per-channel totals
+    float* ssq = s_red + NT * 8;              // [T][8]
+    float* csum = s_red + 2 * NT * 8;         // [nch] per-channel totals
     float* csq = csum + nch;
     float* gstat = csq + nch;                 // [gpb][2] mean, rstd
     if (active) {
@@ -172,12 +173,18 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict_
         for (int j = 0; j < 8; ++j) { ssum[tid * 8 + j] = sum[j]; ssq[tid * 8 + j] = sq[j]; }
     }
     __syncthreads();
-    for (int c = tid; c < nch; c += 256) {    // per-channel: fixed-order sum over the P pixel lanes
-        float a = 0.f, q = 0.f;
-        const int vv = c >> 3, jj = c & 7;
-        for (int p = 0; p < P; ++p) { a += ssum[(p * V + vv) * 8 + jj]; q += ssq[(p * V + vv) * 8 + jj]; }
-        csum[c] = a; csq[c] = q;
+    // fixed-shape tree over the P pixel lanes (deterministic): afterwards lane pl == 0 holds per-channel totals
+    for (int st = 1; st < P; st <<= 1) {
+        if (active && (pl & (2 * st - 1)) == 0 && pl + st < P) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ssum[tid * 8 + j] += ssum[(tid + st * V) * 8 + j];
+                ssq[tid * 8 + j] += ssq[(tid + st * V) * 8 + j];
+            }
+        }
+        __syncthreads();
     }
+    for (int c = tid; c < nch; c += NT) { csum[c] = ssum[c]; csq[c] = ssq[c]; }
     __syncthreads();
     if (tid < gpb) {
         float a = 0.f, q = 0.f;
@@ -308,10 +315,13 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
         if (gpb <= groups) {
             const int nch = gpb * cg;
             const size_t slab = (size_t)hw * nch * sizeof(bf16_t);
-            if (nch / 8 <= 256 && slab <= (size_t)384 * 1024) {
-                const size_t lds = (size_t)(2 * 256 * 8 + 2 * nch + 2 * gpb) * sizeof(float);
+            if (nch / 8 <= 256 && slab <= (size_t)384 * 1024) {   // (V <= 256 <= blockDim)
+                // enough threads that a thread walks <= ~8 pixels (latency-bound otherwise), at most 1024
+                int nt = 256;
+                while (nt < 1024 && (size_t)hw * (nch / 8) > (size_t)nt * 8) nt *= 2;
+                const size_t lds = (size_t)(2 * nt * 8 + 2 * nch + 2 * gpb) * sizeof(float);
                 dim3 grid(groups / gpb, batch);
-                hipLaunchKernelGGL(gn_fused_kernel, grid, dim3(256), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
+                hipLaunchKernelGGL(gn_fused_kernel, grid, dim3(nt), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
                                    hw, C, groups, gpb);
                 MKD_LAUNCH_CHECK("gn_fused_kernel");
                 return 0;

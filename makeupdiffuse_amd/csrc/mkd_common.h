@@ -63,6 +63,15 @@ struct GemmArgs {
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
+// device-resident DDIM step state (hipGraph replay): tables of n_steps entries, counter runs n_steps-1 .. 0
+constexpr int MKD_MAX_STEPS = 1024;
+struct StepState {
+    int counter;
+    float cur[4];                          // sqrt(1/a_t), sqrt(a_prev), sqrt(1-a_prev), sqrt(1-a_t) of the current step
+    int64_t timesteps[MKD_MAX_STEPS];
+    float coef[4 * MKD_MAX_STEPS];
+};
+
 // launchers (each only enqueues on `stream`)
 int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
@@ -93,3 +102,6 @@ int launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, flo
                      float* x_prev, float* pred_x0, int64_t n, hipStream_t stream);
 int launch_repeat_batch(const float* x, float* y, int64_t n_per, int reps, hipStream_t stream);
 int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);
+int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream);
+int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, const StepState* st, int64_t n,
+                           hipStream_t stream);

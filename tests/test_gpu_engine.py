@@ -86,11 +86,21 @@ def test_small_sample_loop(small):
     eng.prepare(g['hint'], g['ctx'])
     out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
     check_eps(out, g['x5'], rel=6e-2, cos=0.99, what='5-step latent')
+    # hipGraph replay of the same loop (one captured step, device-resident step counter) must not change the numbers
+    outg = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                      use_graph=True)
+    assert torch.allclose(outg, out, rtol=1e-5, atol=1e-6), (outg - out).abs().max()
+    outg2 = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                       use_graph=True)          # cached graph, counter re-armed
+    assert torch.equal(outg, outg2)
     # CFG 9: prepared with 2B, unconditional first (cddim.py:25-31), hint shared (diffusion_makeup.py:401)
     eng.prepare(torch.cat([g['hint'], g['hint']]), torch.cat([g['uctx'], g['ctx']]))
     out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                      cfg_scale=9.0)
     check_eps(out, g['x5_cfg'], rel=0.15, cos=0.99, what='5-step CFG latent')
+    outg = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                      cfg_scale=9.0, use_graph=True)
+    assert torch.allclose(outg, out, rtol=1e-5, atol=1e-6), (outg - out).abs().max()
 
 
 def test_param_counts_full():
