@@ -94,6 +94,7 @@ struct mkd_ctx {
 
     // fused weights (built in finalize)
     std::map<std::string, bf16_t*> qkv_w, kv_w;   // by transformer prefix
+    std::map<std::string, bf16_t*> ffg_w; std::map<std::string, float*> ffg_b;   // GEGLU proj with (value, gate) rows interleaved
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
     int emb_total[2] = {0, 0};
@@ -356,7 +357,7 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipMemset(z, 0, 4096));
             zero_page = (bf16_t*)z;
         }
-        qkv_w.clear(); kv_w.clear(); emb_off.clear();
+        qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
@@ -366,6 +367,21 @@ struct mkd_ctx {
                 rc = concat_rows(&k, {t + ".attn2.to_k.weight", t + ".attn2.to_v.weight"});
                 if (rc) return rc;
                 qkv_w[p] = q; kv_w[p] = k;
+                // ff.net.0.proj [8d][d]: rows [0,4d) = value, [4d,8d) = gate  ->  row 2j = value_j, row 2j+1 = gate_j
+                {
+                    const Param& pw = params.at(t + ".ff.net.0.proj.weight");
+                    const Param& pb = params.at(t + ".ff.net.0.proj.bias");
+                    const int64_t inner = pw.shape[0] / 2, kd = pw.shape[1];
+                    void* w2 = nullptr; void* b2 = nullptr;
+                    rc = dev_alloc(&w2, pw.numel() * sizeof(bf16_t)); if (rc) return rc;
+                    rc = dev_alloc(&b2, pb.numel() * sizeof(float)); if (rc) return rc;
+                    const size_t rowb = kd * sizeof(bf16_t);
+                    MKD_HIP_CHECK(hipMemcpy2D(w2, 2 * rowb, pw.dev, rowb, rowb, inner, hipMemcpyDeviceToDevice));
+                    MKD_HIP_CHECK(hipMemcpy2D((char*)w2 + rowb, 2 * rowb, (const char*)pw.dev + inner * rowb, rowb, rowb, inner, hipMemcpyDeviceToDevice));
+                    MKD_HIP_CHECK(hipMemcpy2D(b2, 8, pb.dev, 4, 4, inner, hipMemcpyDeviceToDevice));
+                    MKD_HIP_CHECK(hipMemcpy2D((char*)b2 + 4, 8, (const char*)pb.dev + inner * 4, 4, 4, inner, hipMemcpyDeviceToDevice));
+                    ffg_w[p] = (bf16_t*)w2; ffg_b[p] = (float*)b2;
+                }
             }
             std::vector<std::string> wn;
             int off = 0;
@@ -528,10 +544,8 @@ struct mkd_ctx {
         // GEGLU feed-forward
         bf16_t* n3 = buf(d);
         op_ln(h2, wf(t + ".norm3.weight"), wf(t + ".norm3.bias"), n3, M, d);
-        bf16_t* ff1 = buf(8 * d);
-        { Epi e; e.bias = wf(t + ".ff.net.0.proj.bias"); op_linear(n3, d, M, d, wb(t + ".ff.net.0.proj.weight"), 8 * d, e, ff1, 8 * d); }
-        bf16_t* gg = buf(4 * d);
-        op_geglu(ff1, gg, M, 4 * d);
+        bf16_t* gg = buf(4 * d);     // Linear(d, 8d) + GEGLU in one GEMM: epilogue writes a * gelu(gate), 4d columns
+        { Epi e; e.bias = ffg_b.at(p); e.act = 2; op_linear(n3, d, M, d, ffg_w.at(p), 8 * d, e, gg, 4 * d); }
         bf16_t* h3 = buf(d);
         { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
           op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }

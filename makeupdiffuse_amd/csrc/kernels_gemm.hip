@@ -62,6 +62,13 @@ __device__ __forceinline__ void epilogue_store(const Epilogue e, int m, int n, f
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
     }
+    if (e.act == 2) {
+        // GEGLU with interleaved (value, gate) weight rows: columns (n, n+1) and (n+2, n+3) are two
+        // (a, g) pairs -> out[m, n/2 .. n/2+1] = a * gelu_erf(g); the output has N/2 columns
+        const uint32_t o = (uint32_t)f32_to_bf16(v[0] * gelu_erf_f(v[1])) | ((uint32_t)f32_to_bf16(v[2] * gelu_erf_f(v[3])) << 16);
+        *(uint32_t*)((bf16_t*)e.C + (size_t)m * e.ldc + (n >> 1)) = o;
+        return;
+    }
     if (e.out_f32) {
         *(f32x4*)((float*)e.C + (size_t)m * e.ldc + n) = v;
     } else {
@@ -378,6 +385,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.conv && (a.Cin % 8 || a.K != 9 * a.Cin)) return mkd_fail(-1, "gemm: conv needs Cin % 8 == 0 and K == 9*Cin");
     if (!a.zero) return mkd_fail(-1, "gemm: zero page missing");
     if (!a.out_f32 && (a.ldc % 4)) return mkd_fail(-1, "gemm: ldc must be a multiple of 4");
+    if (a.act == 2 && (a.out_f32 || a.R)) return mkd_fail(-1, "gemm: GEGLU epilogue takes no residual and writes bf16");
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
     const GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);

@@ -116,14 +116,17 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t*
     }
 }
 
-// Single-launch GroupNorm for slabs that stay cache-resident: one workgroup per (sample, chunk of `gpb`
-// groups whose channel span is a multiple of 8).  Pass 1 accumulates per-channel sums in registers, a
-// deterministic 3-stage LDS reduction folds them per group, pass 2 re-reads the slab (L2 hit) and applies.
-__global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
-                                                       int ld_out, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int silu, int hw,
-                                                       int C, int groups, int gpb) {
-    extern __shared__ __attribute__((aligned(16))) float s_red[];    // [2][T][8] then per-channel / per-group
+// Single-launch GroupNorm: one workgroup per (sample, chunk of `gpb` groups whose channel span is a multiple
+// of 8).  NV > 0: the thread's <= NV 16-byte vectors stay in registers between the statistics and the apply, so
+// the slab is read from memory exactly once (one latency round trip).  NV == 0: streaming two-pass variant for
+// slabs that do not fit the register budget (second pass re-reads, L2 hit).  Statistics: per-thread fp32 sums ->
+// LDS -> fixed-shape tree over the pixel lanes (deterministic) -> per-group mean / rstd.
+template <int NV>
+__global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
+                                                        int ld_out, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int silu, int hw,
+                                                        int C, int groups, int gpb) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];    // [2][NT][8] then per-channel / per-group
     const int cg = C / groups;
     const int nch = gpb * cg;                 // channels of this block (multiple of 8)
     const int V = nch >> 3;
@@ -140,31 +143,43 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
     const bf16_t* xin = x + (size_t)b * hw * ld_in + c0 + v * 8;
+    constexpr int NR = NV > 0 ? NV : 1;
+    U16x8 keep[NR];
     if (active) {
-        int r = pl;
-        for (; r + 3 * P < hw; r += 4 * P) {          // 4 independent 16-B loads in flight per thread
-            U16x8 d[4];
+        if (NV > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+            for (int i = 0; i < NR; ++i) {
+                const int r = pl + i * P;
+                if (r < hw) keep[i] = *(const U16x8*)(xin + (size_t)r * ld_in);
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int i = 0; i < NR; ++i) {
+                const int r = pl + i * P;
+                if (r < hw) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = bf16_to_f32(d[u].v[j]);
-                    sum[j] += f; sq[j] += f * f;
+                    for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(keep[i].v[j]); sum[j] += f; sq[j] += f * f; }
                 }
-        }
-        for (; r < hw; r += P) {
-            const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+            }
+        } else {
+            int r = pl;
+            for (; r + 3 * P < hw; r += 4 * P) {          // 4 independent 16-B loads in flight per thread
+                U16x8 d[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = bf16_to_f32(d.v[j]);
-                sum[j] += f; sq[j] += f * f;
+                for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(d[u].v[j]); sum[j] += f; sq[j] += f * f; }
+            }
+            for (; r < hw; r += P) {
+                const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(d.v[j]); sum[j] += f; sq[j] += f * f; }
             }
         }
     }
-    float* ssum = s_red;                      // [T][8]
-    float* ssq = s_red + NT * 8;              // [T][8]
+    float* ssum = s_red;                      // [NT][8]
+    float* ssq = s_red + NT * 8;              // [NT][8]
     float* csum = s_red + 2 * NT * 8;         // [nch] per-channel totals
     float* csq = csum + nch;
     float* gstat = csq + nch;                 // [gpb][2] mean, rstd
@@ -173,7 +188,6 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict
         for (int j = 0; j < 8; ++j) { ssum[tid * 8 + j] = sum[j]; ssq[tid * 8 + j] = sq[j]; }
     }
     __syncthreads();
-    // fixed-shape tree over the P pixel lanes (deterministic): afterwards lane pl == 0 holds per-channel totals
     for (int st = 1; st < P; st <<= 1) {
         if (active && (pl & (2 * st - 1)) == 0 && pl + st < P) {
 #pragma unroll
@@ -208,25 +222,7 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict
         sb[j] = beta[c0 + cl] - gstat[g * 2] * a;
     }
     bf16_t* yout = y + (size_t)b * hw * ld_out + c0 + v * 8;
-    int r = pl;
-    for (; r + 3 * P < hw; r += 4 * P) {
-        U16x8 d[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            U16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = bf16_to_f32(d[u].v[j]) * sa[j] + sb[j];
-                if (silu) f = silu_f(f);
-                o.v[j] = f32_to_bf16(f);
-            }
-            *(U16x8*)(yout + (size_t)(r + u * P) * ld_out) = o;
-        }
-    }
-    for (; r < hw; r += P) {
-        const U16x8 d = *(const U16x8*)(xin + (size_t)r * ld_in);
+    auto apply_store = [&](const U16x8& d, int r) {
         U16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -235,6 +231,23 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const bf16_t* __restrict
             o.v[j] = f32_to_bf16(f);
         }
         *(U16x8*)(yout + (size_t)r * ld_out) = o;
+    };
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = pl + i * P;
+            if (r < hw) apply_store(keep[i], r);
+        }
+    } else {
+        int r = pl;
+        for (; r + 3 * P < hw; r += 4 * P) {
+            U16x8 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) apply_store(d[u], r + u * P);
+        }
+        for (; r < hw; r += P) apply_store(*(const U16x8*)(xin + (size_t)r * ld_in), r);
     }
 }
 
@@ -316,13 +329,26 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
             const int nch = gpb * cg;
             const size_t slab = (size_t)hw * nch * sizeof(bf16_t);
             if (nch / 8 <= 256 && slab <= (size_t)384 * 1024) {   // (V <= 256 <= blockDim)
-                // enough threads that a thread walks <= ~8 pixels (latency-bound otherwise), at most 1024
-                int nt = 256;
-                while (nt < 1024 && (size_t)hw * (nch / 8) > (size_t)nt * 8) nt *= 2;
+                // smallest block (256..1024 threads) whose threads hold their whole share in <= 16 registers-vectors
+                const int V = nch / 8;
+                // 256 / 512 threads with <= 16 vectors per thread, or 1024 threads with <= 8 (register budget);
+                // otherwise the streaming two-pass variant
+                int nt = 256, per = 0;
+                auto per_of = [&](int t) { const int P = t / V; return (hw + P - 1) / P; };
+                if (per_of(256) <= 16) { nt = 256; per = per_of(256); }
+                else if (per_of(512) <= 16) { nt = 512; per = per_of(512); }
+                else if (per_of(1024) <= 8) { nt = 1024; per = per_of(1024); }
+                else { nt = 256; per = 1 << 20; }
                 const size_t lds = (size_t)(2 * nt * 8 + 2 * nch + 2 * gpb) * sizeof(float);
                 dim3 grid(groups / gpb, batch);
-                hipLaunchKernelGGL(gn_fused_kernel, grid, dim3(nt), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
-                                   hw, C, groups, gpb);
+#define MKD_GN_LAUNCH(NVV)                                                                                              \
+    hipLaunchKernelGGL(gn_fused_kernel<NVV>, grid, dim3(nt), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu, hw, C, \
+                       groups, gpb)
+                if (per <= 4) MKD_GN_LAUNCH(4);
+                else if (per <= 8) MKD_GN_LAUNCH(8);
+                else if (per <= 16) MKD_GN_LAUNCH(16);
+                else MKD_GN_LAUNCH(0);
+#undef MKD_GN_LAUNCH
                 MKD_LAUNCH_CHECK("gn_fused_kernel");
                 return 0;
             }

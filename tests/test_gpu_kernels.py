@@ -46,6 +46,24 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
+def test_gemm_fused_geglu():
+    g = torch.Generator().manual_seed(11)
+    for (M, inner, K, splitk) in [(512, 1280, 320, 0), (200, 640, 1280, 2)]:
+        A = bf(torch.randn(M, K, generator=g)); Wv = bf(torch.randn(inner, K, generator=g) / math.sqrt(K))
+        Wg = bf(torch.randn(inner, K, generator=g) / math.sqrt(K))
+        bv = torch.randn(inner, generator=g).to(DEV); bg = torch.randn(inner, generator=g).to(DEV)
+        Wi = torch.stack([Wv, Wg], 1).reshape(2 * inner, K).contiguous()       # rows (v0, g0, v1, g1, ...)
+        bi = torch.stack([bv, bg], 1).reshape(2 * inner).contiguous()
+        lib = L()
+        out = torch.zeros(M, inner, device=DEV, dtype=torch.bfloat16)
+        rc = lib.mkd_gemm_bf16(P(A), K, P(Wi), K, P(bi), None, 0, 1, None, 0, 1.0, 2, P(out), inner, 0, M, 2 * inner, K,
+                               0, 0, 0, 0, 0, 0, 0, 1, 0, splitk, None)
+        assert rc == 0, lib.mkd_last_error()
+        sync()
+        ref = (A.float() @ Wv.float().t() + bv) * F.gelu(A.float() @ Wg.float().t() + bg)
+        assert_close_bf16(out, ref, what='fused geglu')
+
+
 def test_gemm_epilogue_variants():
     g = torch.Generator().manual_seed(7)
     M, N, K, rpb = 512, 640, 640, 128
