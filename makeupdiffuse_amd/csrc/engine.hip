@@ -76,12 +76,15 @@ struct Op {
     int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
 };
 
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 6, K_GROUPNORM = 12, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
-const char* const kKindNames[K_COUNT] = {"gemm_conv3x3_256x128", "gemm_conv3x3_128x128_s3", "gemm_conv3x3_128x128_s2", "gemm_conv3x3_128x64",
-                                         "gemm_conv3x3_64x128", "gemm_conv3x3_64x64",
-                                         "gemm_linear_256x128", "gemm_linear_128x128_s3", "gemm_linear_128x128_s2", "gemm_linear_128x64",
-                                         "gemm_linear_64x128", "gemm_linear_64x64",
-                                         "groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
+// kinds: [0, 12) conv GEMM by tile config, [12, 18) linear GEMM by tile config, then the rest
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 12, K_GROUPNORM = 18, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+
+std::string kind_name(int k) {
+    static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
+    if (k < K_GEMM_LIN) return std::string("gemm_conv3x3_") + gemm_tile_cfg_name(k);
+    if (k < K_GROUPNORM) return std::string("gemm_linear_") + gemm_tile_cfg_name(k - K_GEMM_LIN);
+    return rest[k - K_GROUPNORM];
+}
 
 }  // namespace
 
@@ -909,7 +912,7 @@ struct mkd_ctx {
             if (hipEventElapsedTime(&dt, ev[i], ev[i + 1]) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime"); break; }
             const Op& op = plan_eps[i];
             ms[op.kind] += dt; flops[op.kind] += op.flops; launches[op.kind] += op.launches;
-            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kKindNames[op.kind], op.label.c_str(), dt, op.flops / 1e9);
+            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kind_name(op.kind).c_str(), op.label.c_str(), dt, op.flops / 1e9);
         }
         if (csv) fclose(csv);
         for (auto& e : ev) hipEventDestroy(e);
@@ -1117,7 +1120,12 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
 }
 int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
 int mkd_kind_count(void) { return K_COUNT; }
-const char* mkd_kind_name(int kind) { return (kind >= 0 && kind < K_COUNT) ? kKindNames[kind] : nullptr; }
+const char* mkd_kind_name(int kind) {
+    static thread_local std::string nm;
+    if (kind < 0 || kind >= K_COUNT) return nullptr;
+    nm = kind_name(kind);
+    return nm.c_str();
+}
 int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream, double* ms_per_kind,
                     double* flops_per_kind, int* launches_per_kind, const char* csv_path) {
     if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile: null argument");

@@ -1,0 +1,303 @@
+// 3x3 convolution (stride 1, pad 1) with LDS-staged input tiles on the gfx950 matrix cores.
+// Replaces Conv2d(C, C', 3, padding=1) of every cldm ResBlock / the hint block, reached
+// from diffmk/makeup_diffuse.py:164-168.
+//
+// The generic implicit GEMM (kernels_gemm.hip) gathers each A row per (tap, channel) K-step, so every input
+// pixel travels L2 -> LDS nine times per output-channel tile and the kernel sits on the L2 -> LDS ceiling.
+// Here a workgroup owns a SPATIAL tile (TH x TW pixels of IMGS images = TM rows):
+//   * per 64-channel chunk the haloed patch [(TH+2) x (TW+2)] x 64 ch is loaded ONCE (global_load_lds, zero page
+//     for the padding ring) into a 2-slot LDS buffer;
+//   * the 9 taps are 9 MFMA K-steps whose A fragments are read from the patch at shifted pixel offsets
+//     (ds_read_b128, same XOR swizzle as the GEMM), so only the weights are streamed per tap:
+//     [TN x 64] tiles through a 3-stage ring;
+//   * one raw s_barrier per K-step and counted s_waitcnt vmcnt(N): N = W tiles issued after the one being
+//     waited for (+ the patch pieces when a patch prefetch was issued inside that window) - exact, because
+//     every wave issues a fixed number of loads per tile / per patch;
+//   * output/epilogue as in the GEMM (transposed product, 4 consecutive channels per lane, fused bias /
+//     time-embedding row-bias / residual / split-K over channel chunks).
+// Staged bytes per output drop 2-5x versus the gather and 256-pixel tiles become affordable.
+#include "mkd_common.h"
+#include "gemm_device.h"
+
+namespace {
+
+using namespace mkdk;
+
+template <int TM, int TN, int WM, int WN, int STAGES, int PP>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN;
+    constexpr int WP = TN / 8 / NW;          // W pieces (1 KiB = 8 rows x 128 B) per wave per tile
+    constexpr int NI = TN / WN / 16;
+    constexpr int MI = TM / WM / 16;
+    constexpr int PSLOT = PP * NW * 1024;    // bytes of one patch slot (PP pieces per wave)
+    constexpr int WSB = TN * 128;
+    static_assert(WP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8) && STAGES >= 2 && STAGES <= 4, "layout");
+
+    const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
+    const int lda = p.lda, ldw = p.ldw, M = p.M, N = p.N;
+    const int H = p.Hin, Wd = p.Win, Cin = p.Cin;
+    const int TH = p.tile_h, TW = p.tile_w, IMGS = p.tile_imgs;
+    const int splitk = p.splitk, per = p.ksteps_per_split;      // `per` = channel chunks per split here
+    float* const ws = p.ws;
+    const Epilogue epi = make_epilogue(p);
+    const int batch = M / (H * Wd);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid / 64;
+    const int wm = w / WN, wn = w % WN;
+    const int PH = TH + 2, PW = TW + 2, PPIX = PH * PW, NP = IMGS * PPIX;
+    const int tiles_x = Wd / TW, tiles_y = H / TH;
+    const int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int b0 = (bid / (tiles_x * tiles_y)) * IMGS;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = blockIdx.y * TN;
+    const int nch_total = Cin / BK;
+    const int c_begin = blockIdx.z * per;
+    const int c_end = min(nch_total, c_begin + per);
+
+    char* const patch0 = smem;
+    char* const wring = smem + 2 * PSLOT;
+
+    // ---- staging geometry (same lane -> (row, chunk) map and XOR key as the GEMM) --------------------------
+    const int lrow = lane >> 3;
+    const int key = (4 * (w & 1) + (lane >> 4)) & 7;
+    const int sc = (lane & 7) ^ key;
+
+    size_t poff[PP];
+    bool pok[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int pp = 8 * (w + NW * i) + lrow;           // patch pixel held by this lane's row of piece i
+        const int ppc = pp < NP ? pp : 0;
+        const int img = ppc / PPIX;
+        const int r = ppc - img * PPIX;
+        const int ppy = r / PW, ppx = r - ppy * PW;
+        const int iy = y0 - 1 + ppy, ix = x0 - 1 + ppx, b = b0 + img;
+        pok[i] = pp < NP && b < batch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
+        poff[i] = ((size_t)(b * H + iy) * Wd + ix) * lda + sc * 8;
+    }
+    size_t woff[WP];
+    bool wok[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int n = n0 + 8 * (w + NW * i) + lrow;
+        wok[i] = n < N;
+        woff[i] = (size_t)n * ldw + sc * 8;
+    }
+
+    auto issue_patch = [&](int slot, int c) {
+        char* dst = patch0 + slot * PSLOT;
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+            glds16(select_src(gA + poff[i] + c * BK, gZ, pok[i]), dst + (w + NW * i) * 1024);
+    };
+    auto issue_w = [&](int slot, int c, int tap) {
+        char* dst = wring + slot * WSB;
+        const int k = tap * Cin + c * BK;
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            glds16(select_src(gW + woff[i] + k, gZ, wok[i]), dst + (w + NW * i) * 1024);
+    };
+
+    // ---- MFMA fragment geometry -----------------------------------------------------------------------------
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    int pid0[MI];        // patch pixel of tap (0,0) for this lane's row of fragment mi
+    int mrow[MI];        // global output row (pixel index) or -1
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pr = wm * (TM / WM) + mi * 16 + frow;
+        const int img = pr / (TH * TW);
+        const int r = pr - img * (TH * TW);
+        const int py = r / TW, px = r - py * TW;
+        pid0[mi] = img * PPIX + py * PW + px;
+        const int b = b0 + img;
+        mrow[mi] = b < batch ? (b * H + y0 + py) * Wd + x0 + px : -1;
+    }
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int wslot, int pslot, int tap) {
+        const char* ps = patch0 + pslot * PSLOT;
+        const char* wsm = wring + wslot * WSB;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int dpix = ky * PW + kx;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = 4 * kk + fq;
+            bf16x8 xf[MI], wf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int pidx = pid0[mi] + dpix;
+                xf[mi] = *(const bf16x8*)(ps + pidx * 128 + ((chunk ^ ((pidx >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wn * (TN / WN) + ni * 16 + frow;
+                wf[ni] = *(const bf16x8*)(wsm + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    // ---- K loop over (chunk, tap) ------------------------------------------------------------------------------
+    const int nch = c_end - c_begin;
+    const int nsteps = nch * 9;
+    if (nsteps > 0) {
+        issue_patch(0, c_begin);
+        {
+            int c = 0, tap = 0;
+#pragma unroll
+            for (int s = 0; s < STAGES - 1; ++s) {
+                if (s < nsteps) issue_w(s, c_begin + c, tap);
+                if (++tap == 9) { tap = 0; ++c; }
+            }
+        }
+        int c = 0, tap = 0;                 // step i = (c, tap)
+        int pc = 0, ptap = STAGES - 1;      // step i + STAGES - 1
+        while (ptap >= 9) { ptap -= 9; ++pc; }
+        int wslot = 0, nslot = STAGES - 1;
+        int last_patch = -1000;
+        for (int i = 0; i < nsteps; ++i) {
+            const int after_w = min(STAGES - 2, nsteps - 1 - i);
+            const bool after_p = last_patch >= i - (STAGES - 1);      // a patch prefetch was issued after W(i)
+            switch (after_w * 2 + (after_p ? 1 : 0)) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<PP>(); break;
+                case 2: wait_vmcnt<WP>(); break;
+                case 3: wait_vmcnt<WP + PP>(); break;
+                case 4: wait_vmcnt<2 * WP>(); break;
+                default: wait_vmcnt<2 * WP + PP>(); break;
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + STAGES - 1 < nsteps) issue_w(nslot, c_begin + pc, ptap);
+            if (tap == 0 && c + 1 < nch) { issue_patch((c + 1) & 1, c_begin + c + 1); last_patch = i; }
+            compute(wslot, c & 1, tap);
+            if (++tap == 9) { tap = 0; ++c; }
+            if (++ptap == 9) { ptap = 0; ++pc; }
+            wslot = (wslot + 1 == STAGES) ? 0 : wslot + 1;
+            nslot = (nslot + 1 == STAGES) ? 0 : nslot + 1;
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mrow[mi];
+        if (m < 0) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+            if (n >= N) continue;
+            if (splitk > 1) *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
+            else epilogue_store(epi, m, n, acc[ni][mi]);
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN, int PP>
+int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int STAGES = 3;
+    constexpr int NW = WM * WN;
+    const size_t lds = (size_t)2 * PP * NW * 1024 + (size_t)STAGES * TN * 128;
+    if (lds > 160 * 1024) return mkd_fail(-4, "conv3x3_patch: LDS budget exceeded");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(conv patch LDS): ") + hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP>), grid, dim3(64 * NW), lds, stream, a);
+    return 0;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_patch_pp(const GemmArgs& a, int pp, dim3 grid, hipStream_t stream) {
+    if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream);
+    if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream);
+    if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream);
+    if (pp == 7) return launch_patch<TM, TN, WM, WN, 7>(a, grid, stream);
+    if (pp <= 9) return launch_patch<TM, TN, WM, WN, 9>(a, grid, stream);
+    return mkd_fail(-4, "conv3x3_patch: patch too large");
+}
+
+}  // namespace
+
+// spatial tiling of a TM-row block: TW = min(W, 16), TH = min(H, TM / TW), IMGS images per block
+bool conv_patch_geometry(int tm, int batch, int H, int W, int* th, int* tw, int* imgs, int* pieces_per_wave, int nwaves) {
+    const int TW = W < 16 ? W : 16;
+    if (TW < 4 || W % TW) return false;
+    int TH = tm / TW;
+    if (TH > H) TH = H;
+    if (TH < 1 || H % TH) return false;
+    const int IM = tm / (TH * TW);
+    if (IM < 1 || IM * TH * TW != tm) return false;
+    if (IM > 1 && IM > 2 * batch) return false;          // mostly-empty tiles
+    const int np = IM * (TH + 2) * (TW + 2);
+    int pp = ((np + 7) / 8 + nwaves - 1) / nwaves;
+    if (pp > 9) return false;
+    if (pp < 4) pp = 4;
+    if (pp == 8) pp = 9;
+    *th = TH; *tw = TW; *imgs = IM; *pieces_per_wave = pp;
+    return true;
+}
+
+// cfg: 6: 256x128 (8 waves), 7: 256x64 (8 waves), 8: 128x128, 9: 128x64, 10: 64x128, 11: 64x64 (4 waves)
+bool conv_patch_supported(const GemmArgs& a, int cfg) {
+    if (!a.conv || a.stride != 1 || a.up != 0 || a.Cin % 64 || a.Hin != a.Hout || a.Win != a.Wout) return false;
+    static const int tms[6] = {256, 256, 128, 128, 64, 64};
+    static const int tns[6] = {128, 64, 128, 64, 128, 64};
+    if (cfg < 6 || cfg > 11) return false;
+    const int tm = tms[cfg - 6], tn = tns[cfg - 6], nw = tm == 256 ? 8 : 4;
+    int th, tw, im, pp;
+    if (!conv_patch_geometry(tm, a.M / (a.Hin * a.Win), a.Hin, a.Win, &th, &tw, &im, &pp, nw)) return false;
+    const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)3 * tn * 128;
+    return lds <= 160 * 1024;
+}
+
+int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
+    if (!conv_patch_supported(a, cfg)) return mkd_fail(-4, "conv3x3_patch: unsupported shape for this tile");
+    static const int tms[6] = {256, 256, 128, 128, 64, 64};
+    static const int tns[6] = {128, 64, 128, 64, 128, 64};
+    const int tm = tms[cfg - 6], tn = tns[cfg - 6], nw = tm == 256 ? 8 : 4;
+    const int batch = a.M / (a.Hin * a.Win);
+    int pp;
+    conv_patch_geometry(tm, batch, a.Hin, a.Win, &a.tile_h, &a.tile_w, &a.tile_imgs, &pp, nw);
+    const int nch = a.Cin / 64;
+    int s = splitk < 1 ? 1 : splitk;
+    if (s > nch) s = nch;
+    const int per = (nch + s - 1) / s;
+    s = (nch + per - 1) / per;
+    if (s > 1 && !a.ws) return mkd_fail(-1, "conv3x3_patch: split-K needs a workspace");
+    a.splitk = s;
+    a.ksteps_per_split = per;
+    const int groups = (batch + a.tile_imgs - 1) / a.tile_imgs;
+    dim3 grid(groups * (a.Hin / a.tile_h) * (a.Win / a.tile_w), (a.N + tn - 1) / tn, s);
+    int rc;
+    switch (cfg) {
+        case 6: rc = launch_patch_pp<256, 128, 4, 2>(a, pp, grid, stream); break;
+        case 7: rc = launch_patch_pp<256, 64, 4, 2>(a, pp, grid, stream); break;
+        case 8: rc = launch_patch_pp<128, 128, 2, 2>(a, pp, grid, stream); break;
+        case 9: rc = launch_patch_pp<128, 64, 2, 2>(a, pp, grid, stream); break;
+        case 10: rc = launch_patch_pp<64, 128, 2, 2>(a, pp, grid, stream); break;
+        default: rc = launch_patch_pp<64, 64, 2, 2>(a, pp, grid, stream); break;
+    }
+    if (rc) return rc;
+    MKD_LAUNCH_CHECK("conv3x3_patch_kernel");
+    if (s > 1) return launch_splitk_epilogue(a, stream);
+    return 0;
+}

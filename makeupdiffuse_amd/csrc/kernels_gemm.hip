@@ -20,67 +20,11 @@
 //   * small-M layers (4x4 / 8x8 latents) are weight-bandwidth bound: split-K over blockIdx.z with
 //     fp32 partial slabs + a fused reduce/epilogue kernel fills the 256 CUs.
 #include "mkd_common.h"
+#include "gemm_device.h"
 
 namespace {
 
-constexpr int BK = 64;
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
-}
-
-// branch-free select of a load source, made opaque so the compiler keeps ONE global_load_lds per call site
-// (a duplicated load would break the exact loads-per-tile count the counted vmcnt waits rely on).
-__device__ __forceinline__ const void* select_src(const void* real, const void* zero, bool ok) {
-    unsigned long long v = ok ? (unsigned long long)real : (unsigned long long)zero;
-    asm volatile("" : "+v"(v));
-    return (const void*)v;
-}
-
-struct Epilogue {
-    const float* bias; const float* rowbias; int ldrb; int rpb;
-    const bf16_t* R; int ldr; float scale; int act; void* C; int ldc; int out_f32;
-};
-
-__device__ __forceinline__ Epilogue make_epilogue(const GemmArgs& p) {
-    return Epilogue{p.bias, p.rowbias, p.ldrb, p.rows_per_batch, p.R, p.ldr, p.scale, p.act, p.C, p.ldc, p.out_f32};
-}
-
-__device__ __forceinline__ void epilogue_store(const Epilogue e, int m, int n, f32x4 v) {
-    if (e.bias) v += *(const f32x4*)(e.bias + n);
-    if (e.rowbias) v += *(const f32x4*)(e.rowbias + (size_t)(m / e.rpb) * e.ldrb + n);
-    v *= e.scale;
-    if (e.R) {
-        const U16x4 r = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r.v[j]);
-    }
-    if (e.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-    }
-    if (e.act == 2) {
-        // GEGLU with interleaved (value, gate) weight rows: columns (n, n+1) and (n+2, n+3) are two
-        // (a, g) pairs -> out[m, n/2 .. n/2+1] = a * gelu_erf(g); the output has N/2 columns
-        const uint32_t o = (uint32_t)f32_to_bf16(v[0] * gelu_erf_f(v[1])) | ((uint32_t)f32_to_bf16(v[2] * gelu_erf_f(v[3])) << 16);
-        *(uint32_t*)((bf16_t*)e.C + (size_t)m * e.ldc + (n >> 1)) = o;
-        return;
-    }
-    if (e.out_f32) {
-        *(f32x4*)((float*)e.C + (size_t)m * e.ldc + n) = v;
-    } else {
-        U16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o.v[j] = f32_to_bf16(v[j]);
-        *(U16x4*)((bf16_t*)e.C + (size_t)m * e.ldc + n) = o;
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+using namespace mkdk;
 
 template <int TM, int TN, int WM, int WN, int CONV, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
@@ -287,9 +231,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 //   3: 128x64  4 waves (2x2) 3 stages   72 KiB        2 blocks/CU  43
 //   4: 64x128  4 waves (2x2) 3 stages   72 KiB        2 blocks/CU  43
 //   5: 64x64   4 waves (2x2) 4 stages   64 KiB        2 blocks/CU  32
-constexpr int N_TILE_CFG = 6;
-static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64};
-static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64};
+//   6..11: LDS-staged 3x3 conv tiles (kernels_conv.hip): 256x128, 256x64 (8 waves), 128x128, 128x64, 64x128, 64x64
+constexpr int N_TILE_CFG = 12;
+constexpr int N_GATHER_CFG = 6;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64};
+static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
+                                                  "patch256x128", "patch256x64", "patch128x128", "patch128x64",
+                                                  "patch64x128", "patch64x64"};
+int gemm_num_tile_cfgs() { return N_TILE_CFG; }
+const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
 
 struct GemmPlan { int cfg, splitk, per; };
 
@@ -318,9 +269,20 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
     if (te) {
         GemmPlan g;
         g.cfg = te->cfg;
-        const int s0 = te->splitk < nk ? te->splitk : nk;
-        g.per = (nk + s0 - 1) / s0;
-        g.splitk = (nk + g.per - 1) / g.per;
+        const int units = te->cfg >= N_GATHER_CFG ? (K / 9) / BK : nk;     // patch conv splits over channel chunks
+        const int s0 = te->splitk < units ? te->splitk : units;
+        g.per = (units + s0 - 1) / s0;
+        g.splitk = (units + g.per - 1) / g.per;
+        return g;
+    }
+    if (g_force_cfg >= N_GATHER_CFG) {
+        GemmPlan g;
+        g.cfg = g_force_cfg;
+        const int units = (K / 9) / BK > 0 ? (K / 9) / BK : 1;
+        int s0 = force_splitk > 0 ? force_splitk : 1;
+        if (s0 > units) s0 = units;
+        g.per = (units + s0 - 1) / s0;
+        g.splitk = (units + g.per - 1) / g.per;
         return g;
     }
     if (g_force_cfg >= 0) cfg = g_force_cfg;
@@ -388,7 +350,15 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.act == 2 && (a.out_f32 || a.R)) return mkd_fail(-1, "gemm: GEGLU epilogue takes no residual and writes bf16");
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
-    const GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+    GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+    if (g.cfg >= N_GATHER_CFG) {
+        if (conv_patch_supported(a, g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
+        if (g_force_cfg >= N_GATHER_CFG) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
+        const int keep = g_force_cfg;                 // tuned entry from another geometry: fall back to the heuristic
+        g_force_cfg = 1;
+        g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0);
+        g_force_cfg = keep;
+    }
     if (g.splitk > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
     a.splitk = g.splitk;
     a.ksteps_per_split = g.per;
@@ -403,10 +373,13 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("gemm_kernel");
-    if (g.splitk > 1) {
-        dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
-        hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, a);
-        MKD_LAUNCH_CHECK("splitk_epilogue_kernel");
-    }
+    if (g.splitk > 1) return launch_splitk_epilogue(a, stream);
+    return 0;
+}
+
+int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream) {
+    dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, a);
+    MKD_LAUNCH_CHECK("splitk_epilogue_kernel");
     return 0;
 }

@@ -60,6 +60,7 @@ struct GemmArgs {
     int M, N, K;
     int conv; int Hin, Win, Cin, Hout, Wout, stride, up;
     float* ws; int splitk; int ksteps_per_split;
+    int tile_h, tile_w, tile_imgs;          // spatial tile of the LDS-staged conv kernel (set by its launcher)
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
@@ -77,6 +78,11 @@ int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
+int  gemm_num_tile_cfgs();
+const char* gemm_tile_cfg_name(int cfg);
+int  launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream);
+bool conv_patch_supported(const GemmArgs& a, int cfg);
+int  launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream);
 size_t gemm_ws_bytes(int M, int N, int splitk);
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,

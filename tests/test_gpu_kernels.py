@@ -116,6 +116,42 @@ def test_gemm_conv3x3(B, H, W_, Cin, Cout, stride, up, pad_ld, splitk):
     assert_close_bf16(out, ref, what='conv3x3')
 
 
+@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('B,H,W_,Cin,Cout,pad_ld,splitk', [(2, 32, 32, 64, 128, 0, 1), (8, 4, 4, 1280, 1280, 0, 5), (3, 8, 8, 320, 320, 64, 1),
+                                                          (2, 16, 16, 128, 64, 0, 2), (1, 32, 32, 320, 320, 0, 1), (8, 8, 8, 640, 1280, 0, 3),
+                                                          (5, 4, 4, 128, 192, 0, 1), (2, 64, 64, 64, 64, 0, 1)])
+def test_conv3x3_lds_staged_tiles(cfg, B, H, W_, Cin, Cout, pad_ld, splitk):
+    """every LDS-staged 3x3 tile configuration (kernels_conv.hip) vs torch conv2d, incl. ragged image groups, padded
+    pixel stride, split-K over channel chunks, fused bias + per-sample row-bias + residual."""
+    lib = L()
+    g = torch.Generator().manual_seed(cfg * 131 + B * H + Cin)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    rowbias = torch.randn(B, Cout, generator=g).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    ld = Cin + pad_ld
+    xn = torch.full((B, H, W_, ld), 99.0, device=DEV, dtype=torch.bfloat16)
+    xn[..., :Cin] = xb.permute(0, 2, 3, 1)
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(wbf.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    R = bf(torch.randn(B * H * W_, Cout, generator=g))
+    ref = F.conv2d(xb.float(), wbf.float(), bias, padding=1) + rowbias[:, :, None, None]
+    ref = ref + R.float().view(B, H, W_, Cout).permute(0, 3, 1, 2)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        out = torch.zeros(B * H * W_, Cout, device=DEV, dtype=torch.bfloat16)
+        rc = lib.mkd_gemm_bf16(P(xn), ld, P(wp), 9 * Cin, P(bias), P(rowbias), Cout, H * W_, P(R), Cout, 1.0, 0, P(out), Cout, 0,
+                               B * H * W_, Cout, 9 * Cin, 1, B, H, W_, Cin, H, W_, 1, 0, splitk, None)
+        if rc == -4:
+            pytest.skip('tile configuration does not fit this geometry: ' + lib.mkd_last_error().decode())
+        assert rc == 0, lib.mkd_last_error()
+        sync()
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert_close_bf16(out.float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what=f'patch conv cfg {cfg}')
+
+
 @pytest.mark.parametrize('B,hw,C,silu,eps,pad', [(2, 64, 320, 1, 1e-5, 0), (3, 256, 640, 0, 1e-6, 0), (2, 16, 2560, 1, 1e-5, 0),
                                                 (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0), (1, 4096, 960, 1, 1e-5, 0), (2, 4096, 320, 0, 1e-5, 0),
                                                 (1, 64, 1920, 1, 1e-5, 0)])

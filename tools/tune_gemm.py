@@ -22,8 +22,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 
 DEV = 'cuda:0'
-TILE_M = [256, 128, 128, 128, 64, 64]
-TILE_N = [128, 128, 128, 64, 128, 64]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64]
 POOL_BYTES = 640 << 20
 
 
@@ -97,12 +97,16 @@ def main():
         t_def = time_cfg(lib, shape, -1, 0, pool, A, out)
         best = (None, None, 1e30)
         trials = []
-        for cfg in range(6):
+        for cfg in range(12):
             if N % 128 and TILE_N[cfg] == 128 and N < 128:
                 continue
+            patch = cfg >= 6
+            if patch and not (conv and stride == 1 and up == 0 and Cin % 64 == 0):
+                continue
             tiles = -(-M // TILE_M[cfg]) * -(-N // TILE_N[cfg])
-            for s in (1, 2, 3, 4, 6, 8, 12, 16, 24):
-                if s > 1 and (nk // s < 2 or tiles * s > 2048 or tiles >= 512):
+            units = Cin // 64 if patch else nk
+            for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24):
+                if s > 1 and (units // s < (1 if patch else 2) or tiles * s > 2048 or tiles >= 512):
                     continue
                 if s > 1 and s * M * N * 4 > (256 << 20):
                     continue
