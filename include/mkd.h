@@ -133,6 +133,19 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
                   void* C, int ldc, int out_f32, int M, int N, int K,
                   int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
                   int stride, int up, int splitk, void* stream);
+/* LayerNorm fused into a linear GEMM: C = act(LN(A) . W^T + b) computed as rstd*(A.W'^T - mu*s) + b' on the RAW rows of A.
+ * mkd_fold_layernorm builds W' = bf16(W*gamma) (written to rows dst_row0 + n*dst_row_mul of w_out), s = rowsum(W'),
+ * b' = bias + W.beta from fp32 W [N,K] (device).  mkd_gemm_ln_bf16 runs the fused GEMM (no split-K); the row sums
+ * come from the GEMM that produced A: row_stats [stat_slots][M][2] = partial (sum, sum of squares) per column slot.
+ * mkd_gemm_rowstats_bf16 is that producer: C = A.W^T + bias + R (bf16) and the partial row sums of the rounded C. */
+int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
+                       uint16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, void* stream);
+int mkd_gemm_ln_bf16(const uint16_t* A, int lda, const uint16_t* Wfold, int ldw, const float* bias_fold, const float* ln_s,
+                     const float* row_stats, int stat_slots, float eps, int act, void* C, int ldc, int M, int N, int K,
+                     void* stream);
+int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* R, int ldr,
+                           uint16_t* C, int ldc, int M, int N, int K, float* stat_out, int stat_capacity_slots, int* slots_out,
+                           void* stream);
 /* Tuner / tests only: force the GEMM tile configuration (index into the table in kernels_gemm.hip; -1 = heuristic). */
 int mkd_gemm_force_tile(int cfg);
 /* GroupNorm(32 groups, fp32 statistics) [+SiLU] over NHWC bf16 (pixel stride ld_in). */

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
@@ -63,6 +64,9 @@ struct Epi {
     const float* rowbias = nullptr; int ldrb = 0; int rpb = 1;
     const bf16_t* R = nullptr; int ldr = 0;
     float scale = 1.f; int act = 0;
+    const float* ln_s = nullptr;          // fused LayerNorm of the A rows (weights pre-folded with gamma/beta)
+    const float* stat_in = nullptr; int stat_slots = 0;   // ... with the row sums the producer GEMM emitted
+    float* stat_out = nullptr;            // emit row sums of this GEMM's output for a downstream fused LayerNorm
 };
 
 typedef std::function<int(hipStream_t)> OpFn;
@@ -94,10 +98,18 @@ struct mkd_ctx {
     std::vector<std::string> res_prefixes[2];     // per net, in execution order
     std::vector<std::string> st_prefixes[2];
     bool finalized = false;
+    // LayerNorm folded into its consumer GEMMs (row sums emitted by the producer GEMM's epilogue).  Correct and tested,
+    // but measured neutral-to-slower in the pipeline (the consumer inherits the producer's write-back wait that the
+    // LayerNorm kernel used to absorb), so it is opt-in: MKD_FUSE_LN=1.
+    bool fuse_ln = false;
 
     // fused weights (built in finalize)
     std::map<std::string, bf16_t*> qkv_w, kv_w;   // by transformer prefix
     std::map<std::string, bf16_t*> ffg_w; std::map<std::string, float*> ffg_b;   // GEGLU proj with (value, gate) rows interleaved
+    // LayerNorm folded into its consumer GEMMs: W' = W*gamma (bf16), s = rowsum(W'), b' = b + W.beta
+    std::map<std::string, bf16_t*> q2_w; std::map<std::string, float*> qkv_s, qkv_b, q2_s, q2_b, ffg_s;
+    std::map<std::string, bf16_t*> qkv_plain, ffp_w; std::map<std::string, float*> ffp_b;     // the unfolded counterparts
+    std::map<std::string, float*> f32_keep;      // fp32 copies of the weights that get folded (kept for re-finalize)
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
     int emb_total[2] = {0, 0};
@@ -325,7 +337,16 @@ struct mkd_ctx {
             }
         }
         e = hipDeviceSynchronize();
-        hipFree(stage);
+        const std::string nm(name);
+        auto ends = [&](const char* suf) { const size_t L = strlen(suf); return nm.size() >= L && nm.compare(nm.size() - L, L, suf) == 0; };
+        if (!rc && e == hipSuccess && (ends(".attn1.to_q.weight") || ends(".attn1.to_k.weight") || ends(".attn1.to_v.weight") ||
+                                      ends(".attn2.to_q.weight") || ends(".ff.net.0.proj.weight"))) {
+            auto it2 = f32_keep.find(nm);
+            if (it2 != f32_keep.end()) hipFree(it2->second); else weight_bytes += n * (int64_t)sizeof(float);
+            f32_keep[nm] = stage;
+        } else {
+            hipFree(stage);
+        }
         if (rc) return rc;
         if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("load_weight sync: ") + hipGetErrorString(e));
         p.loaded = true;
@@ -361,17 +382,19 @@ struct mkd_ctx {
             zero_page = (bf16_t*)z;
         }
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
+        q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
-                bf16_t* q = nullptr; bf16_t* k = nullptr;
-                int rc = concat_rows(&q, {t + ".attn1.to_q.weight", t + ".attn1.to_k.weight", t + ".attn1.to_v.weight"});
+                bf16_t* k = nullptr;
+                int rc = concat_rows(&k, {t + ".attn2.to_k.weight", t + ".attn2.to_v.weight"});
                 if (rc) return rc;
-                rc = concat_rows(&k, {t + ".attn2.to_k.weight", t + ".attn2.to_v.weight"});
-                if (rc) return rc;
-                qkv_w[p] = q; kv_w[p] = k;
-                // ff.net.0.proj [8d][d]: rows [0,4d) = value, [4d,8d) = gate  ->  row 2j = value_j, row 2j+1 = gate_j
-                {
+                kv_w[p] = k;
+                {   // unfolded: [to_q; to_k; to_v] and the (value, gate)-interleaved GEGLU projection
+                    bf16_t* q = nullptr;
+                    rc = concat_rows(&q, {t + ".attn1.to_q.weight", t + ".attn1.to_k.weight", t + ".attn1.to_v.weight"});
+                    if (rc) return rc;
+                    qkv_plain[p] = q;
                     const Param& pw = params.at(t + ".ff.net.0.proj.weight");
                     const Param& pb = params.at(t + ".ff.net.0.proj.bias");
                     const int64_t inner = pw.shape[0] / 2, kd = pw.shape[1];
@@ -383,7 +406,58 @@ struct mkd_ctx {
                     MKD_HIP_CHECK(hipMemcpy2D((char*)w2 + rowb, 2 * rowb, (const char*)pw.dev + inner * rowb, rowb, rowb, inner, hipMemcpyDeviceToDevice));
                     MKD_HIP_CHECK(hipMemcpy2D(b2, 8, pb.dev, 4, 4, inner, hipMemcpyDeviceToDevice));
                     MKD_HIP_CHECK(hipMemcpy2D((char*)b2 + 4, 8, (const char*)pb.dev + inner * 4, 4, 4, inner, hipMemcpyDeviceToDevice));
-                    ffg_w[p] = (bf16_t*)w2; ffg_b[p] = (float*)b2;
+                    ffp_w[p] = (bf16_t*)w2; ffp_b[p] = (float*)b2;
+                }
+                const int d = (int)params.at(p + ".norm.weight").numel();
+                auto keep = [&](const std::string& n) -> const float* {
+                    auto it = f32_keep.find(n);
+                    return it == f32_keep.end() ? nullptr : it->second;
+                };
+                auto fvec = [&](int n, float** out) { void* v = nullptr; int r = dev_alloc(&v, (size_t)n * sizeof(float)); *out = (float*)v; return r; };
+                // attn1: [to_q; to_k; to_v] . LN1
+                {
+                    void* wq = nullptr; float* sv = nullptr; float* bv = nullptr;
+                    rc = dev_alloc(&wq, (size_t)3 * d * d * sizeof(bf16_t)); if (rc) return rc;
+                    rc = fvec(3 * d, &sv); if (rc) return rc;
+                    rc = fvec(3 * d, &bv); if (rc) return rc;
+                    const char* parts[3] = {".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight"};
+                    for (int j = 0; j < 3; ++j) {
+                        const float* wsrc = keep(t + parts[j]);
+                        if (!wsrc) return mkd_fail(MKD_ERR_MISSING, "fp32 copy missing for " + t + parts[j]);
+                        rc = launch_fold_layernorm(wsrc, wf(t + ".norm1.weight"), wf(t + ".norm1.bias"), nullptr, d, d, (bf16_t*)wq,
+                                                   j * d, 1, sv, bv, 0);
+                        if (rc) return rc;
+                    }
+                    qkv_w[p] = (bf16_t*)wq; qkv_s[p] = sv; qkv_b[p] = bv;
+                }
+                // attn2.to_q . LN2
+                {
+                    void* wq = nullptr; float* sv = nullptr; float* bv = nullptr;
+                    rc = dev_alloc(&wq, (size_t)d * d * sizeof(bf16_t)); if (rc) return rc;
+                    rc = fvec(d, &sv); if (rc) return rc;
+                    rc = fvec(d, &bv); if (rc) return rc;
+                    const float* wsrc = keep(t + ".attn2.to_q.weight");
+                    if (!wsrc) return mkd_fail(MKD_ERR_MISSING, "fp32 copy missing for " + t + ".attn2.to_q.weight");
+                    rc = launch_fold_layernorm(wsrc, wf(t + ".norm2.weight"), wf(t + ".norm2.bias"), nullptr, d, d, (bf16_t*)wq, 0, 1, sv, bv, 0);
+                    if (rc) return rc;
+                    q2_w[p] = (bf16_t*)wq; q2_s[p] = sv; q2_b[p] = bv;
+                }
+                // ff.net.0.proj [8d][d] . LN3: rows [0,4d) = value, [4d,8d) = gate  ->  row 2j = value_j, row 2j+1 = gate_j
+                {
+                    const int inner = 4 * d;
+                    void* w2 = nullptr; float* sv = nullptr; float* bv = nullptr;
+                    rc = dev_alloc(&w2, (size_t)2 * inner * d * sizeof(bf16_t)); if (rc) return rc;
+                    rc = fvec(2 * inner, &sv); if (rc) return rc;
+                    rc = fvec(2 * inner, &bv); if (rc) return rc;
+                    const float* wsrc = keep(t + ".ff.net.0.proj.weight");
+                    if (!wsrc) return mkd_fail(MKD_ERR_MISSING, "fp32 copy missing for " + t + ".ff.net.0.proj.weight");
+                    const float* bsrc = wf(t + ".ff.net.0.proj.bias");
+                    for (int half = 0; half < 2; ++half) {
+                        rc = launch_fold_layernorm(wsrc + (size_t)half * inner * d, wf(t + ".norm3.weight"), wf(t + ".norm3.bias"),
+                                                   bsrc + half * inner, inner, d, (bf16_t*)w2, half, 2, sv, bv, 0);
+                        if (rc) return rc;
+                    }
+                    ffg_w[p] = (bf16_t*)w2; ffg_b[p] = bv; ffg_s[p] = sv;
                 }
             }
             std::vector<std::string> wn;
@@ -448,6 +522,7 @@ struct mkd_ctx {
         a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = e.bias; a.rowbias = e.rowbias; a.ldrb = e.ldrb;
         a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
         a.C = C; a.ldc = ldc; a.out_f32 = f32out ? 1 : 0; a.M = M; a.N = N; a.K = K; a.conv = 0;
+        a.ln_s = e.ln_s; a.ln_eps = 1e-5f; a.stat_in = e.stat_in; a.stat_in_slots = e.stat_slots; a.stat_out = e.stat_out;
         op_gemm(a);
     }
     // 3x3 conv, pad 1; returns output spatial dims through Hout/Wout
@@ -521,34 +596,48 @@ struct mkd_ctx {
         auto buf = [&](int cols) { return (bf16_t*)TA().alloc((size_t)M * cols * sizeof(bf16_t)); };
         bf16_t* g = buf(d);
         op_gn(x, wf(p + ".norm.weight"), wf(p + ".norm.bias"), 1e-6f, 0, g, d);
+        // Two variants.  fuse_ln: LayerNorm1/2/3 never run as kernels - the GEMM that PRODUCES h0/h1/h2 emits per-column-
+        // tile partial row sums of its rounded output and the GEMM that CONSUMES LN(h) applies rstd*(acc - mu*rowsum(W'))
+        // in its epilogue.  Default: LayerNorm kernels feeding the same folded... no: the plain weights.
+        const int slots = gemm_stat_slots(M, d, d);
+        const bool fl = fuse_ln && slots <= 20;
+        auto sbuf = [&]() { return fl ? (float*)TA().alloc((size_t)slots * M * 2 * sizeof(float)) : nullptr; };
+        float* st0 = sbuf(); float* st1 = sbuf(); float* st2 = sbuf();
+        auto ln_input = [&](const bf16_t* hsrc, const std::string& norm) -> const bf16_t* {      // plain path: LN kernel
+            if (fl) return hsrc;
+            bf16_t* y = buf(d);
+            op_ln(hsrc, wf(t + norm + ".weight"), wf(t + norm + ".bias"), y, M, d);
+            return y;
+        };
         bf16_t* h0 = buf(d);
-        { Epi e; e.bias = wf(p + ".proj_in.bias"); op_linear(g, d, M, d, wb(p + ".proj_in.weight"), d, e, h0, d); }
+        { Epi e; e.bias = wf(p + ".proj_in.bias"); e.stat_out = st0; op_linear(g, d, M, d, wb(p + ".proj_in.weight"), d, e, h0, d); }
         // self attention
-        bf16_t* n1 = buf(d);
-        op_ln(h0, wf(t + ".norm1.weight"), wf(t + ".norm1.bias"), n1, M, d);
         bf16_t* qkv = buf(3 * d);
-        { Epi e; op_linear(n1, d, M, d, qkv_w.at(p), 3 * d, e, qkv, 3 * d); }
+        { Epi e; const bf16_t* a_in = ln_input(h0, ".norm1");
+          if (fl) { e.bias = qkv_b.at(p); e.ln_s = qkv_s.at(p); e.stat_in = st0; e.stat_slots = slots; }
+          op_linear(a_in, d, M, d, fl ? qkv_w.at(p) : qkv_plain.at(p), 3 * d, e, qkv, 3 * d); }
         bf16_t* a1 = buf(d);
         op_attn(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, a1, d, x.B, T, T, heads, dh);
         bf16_t* h1 = buf(d);
-        { Epi e; e.bias = wf(t + ".attn1.to_out.0.bias"); e.R = h0; e.ldr = d;
+        { Epi e; e.bias = wf(t + ".attn1.to_out.0.bias"); e.R = h0; e.ldr = d; e.stat_out = st1;
           op_linear(a1, d, M, d, wb(t + ".attn1.to_out.0.weight"), d, e, h1, d); }
         // cross attention (K/V cached at prepare)
-        bf16_t* n2 = buf(d);
-        op_ln(h1, wf(t + ".norm2.weight"), wf(t + ".norm2.bias"), n2, M, d);
         bf16_t* q2 = buf(d);
-        { Epi e; op_linear(n2, d, M, d, wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
+        { Epi e; const bf16_t* a_in = ln_input(h1, ".norm2");
+          if (fl) { e.bias = q2_b.at(p); e.ln_s = q2_s.at(p); e.stat_in = st1; e.stat_slots = slots; }
+          op_linear(a_in, d, M, d, fl ? q2_w.at(p) : wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
         const Tensor& kv = kv_cache.at(p);
         bf16_t* a2 = buf(d);
         op_attn(q2, d, kv.p, 2 * d, kv.p + d, 2 * d, a2, d, x.B, T, ctx_len(), heads, dh);
         bf16_t* h2 = buf(d);
-        { Epi e; e.bias = wf(t + ".attn2.to_out.0.bias"); e.R = h1; e.ldr = d;
+        { Epi e; e.bias = wf(t + ".attn2.to_out.0.bias"); e.R = h1; e.ldr = d; e.stat_out = st2;
           op_linear(a2, d, M, d, wb(t + ".attn2.to_out.0.weight"), d, e, h2, d); }
-        // GEGLU feed-forward
-        bf16_t* n3 = buf(d);
-        op_ln(h2, wf(t + ".norm3.weight"), wf(t + ".norm3.bias"), n3, M, d);
-        bf16_t* gg = buf(4 * d);     // Linear(d, 8d) + GEGLU in one GEMM: epilogue writes a * gelu(gate), 4d columns
-        { Epi e; e.bias = ffg_b.at(p); e.act = 2; op_linear(n3, d, M, d, ffg_w.at(p), 8 * d, e, gg, 4 * d); }
+        // GEGLU feed-forward: Linear(d, 8d) + GEGLU in one GEMM (epilogue writes a * gelu(gate), 4d columns)
+        bf16_t* gg = buf(4 * d);
+        { Epi e; const bf16_t* a_in = ln_input(h2, ".norm3"); e.act = 2;
+          if (fl) { e.bias = ffg_b.at(p); e.ln_s = ffg_s.at(p); e.stat_in = st2; e.stat_slots = slots; }
+          else e.bias = ffp_b.at(p);
+          op_linear(a_in, d, M, d, fl ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, 4 * d); }
         bf16_t* h3 = buf(d);
         { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
           op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
@@ -1022,6 +1111,7 @@ struct mkd_ctx {
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
+        for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
         if (h_state) hipHostFree(h_state);
@@ -1060,6 +1150,7 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
         return mkd_fail(MKD_ERR_HIP, "no HIP device visible: libmkd has no CPU path");
     mkd_ctx* c = new mkd_ctx();
     c->cfg = *cfg;
+    if (const char* fl = getenv("MKD_FUSE_LN")) c->fuse_ln = fl[0] == '1';
     c->build_param_spec();
     *out = c;
     return 0;
@@ -1167,6 +1258,44 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
     int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
     if (rc) return rc;
     a.ws = g_ws; a.splitk = s;
+    return launch_gemm(a, (hipStream_t)stream);
+}
+int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K, uint16_t* w_out,
+                       int dst_row0, int dst_row_mul, float* s_out, float* b_out, void* stream) {
+    if (!w || !gamma || !beta || !w_out || !s_out || !b_out) return mkd_fail(MKD_ERR_ARG, "mkd_fold_layernorm: null pointer");
+    return launch_fold_layernorm(w, gamma, beta, bias, N, K, w_out, dst_row0, dst_row_mul, s_out, b_out, (hipStream_t)stream);
+}
+int mkd_gemm_ln_bf16(const uint16_t* A, int lda, const uint16_t* Wfold, int ldw, const float* bias_fold, const float* ln_s,
+                     const float* row_stats, int stat_slots, float eps, int act, void* C, int ldc, int M, int N, int K, void* stream) {
+    if (!A || !Wfold || !C || !ln_s || !row_stats) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_ln_bf16: null pointer");
+    if (!g_zero) {
+        MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
+        MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));
+    }
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = Wfold; a.ldw = ldw; a.bias = bias_fold; a.scale = 1.f; a.act = act; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.rows_per_batch = 1; a.zero = g_zero; a.ln_s = ln_s; a.ln_eps = eps;
+    a.stat_in = row_stats; a.stat_in_slots = stat_slots;
+    return launch_gemm(a, (hipStream_t)stream);
+}
+int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* R, int ldr,
+                           uint16_t* C, int ldc, int M, int N, int K, float* stat_out, int stat_capacity_slots, int* slots_out,
+                           void* stream) {
+    if (!A || !W || !C || !stat_out || !slots_out) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_rowstats_bf16: null pointer");
+    if (!g_zero) {
+        MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
+        MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));
+    }
+    const int slots = gemm_stat_slots(M, N, K);
+    if (slots > stat_capacity_slots) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_rowstats_bf16: statistics buffer too small");
+    *slots_out = slots;
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.scale = 1.f; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.rows_per_batch = 1; a.zero = g_zero; a.stat_out = stat_out;
+    const int s = gemm_pick_splitk(M, N, K, 0, 0, 0);
+    int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    if (rc) return rc;
+    a.ws = g_ws;
     return launch_gemm(a, (hipStream_t)stream);
 }
 int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,

@@ -26,7 +26,7 @@ namespace {
 
 using namespace mkdk;
 
-template <int TM, int TN, int WM, int WN, int CONV, int STAGES>
+template <int TM, int TN, int WM, int WN, int CONV, int STAGES, int LN = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XS = TM * 128;          // bytes of one X stage (TM rows x 64 bf16)
@@ -47,6 +47,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     const int splitk = p.splitk, per = p.ksteps_per_split;
     float* const ws = p.ws;
     const Epilogue epi = make_epilogue(p);
+    const float ln_eps = p.ln_eps;
+    const float* const ln_s = p.ln_s;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,6 +162,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
         }
     };
 
+    const float* const stat_in = p.stat_in; const int stat_in_slots = p.stat_in_slots;
+    float* const stat_out = p.stat_out;
+    constexpr int SL = LN > 0 ? LN : 1;          // LN = 0: off; 1 / 3 / 5: stat loads per lane per row
+    float2 lnt[LN ? MI : 1][SL];
+
     // ---- K loop: STAGES-deep LDS ring, STAGES-1 tiles of global_load_lds in flight across each barrier ----
     // Every wave issues exactly LPT loads per tile, in order, so "tile i landed" == "at most LPT * (tiles
     // issued after i) of my loads are still outstanding": a counted s_waitcnt, never a full drain.
@@ -168,13 +175,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < ntile) stage(s, kt_begin + s);
+        // fused LayerNorm: row statistics are issued AFTER the prologue tiles and consumed after the loop.  Loads
+        // retire in order, so issued earlier they would hold up the first tile wait of every block (their lines
+        // were just written by the producer GEMM, possibly through another XCD's L2).  Being younger than tiles
+        // 0..STAGES-2 they add a constant NST to the counted waits of the first STAGES-1 iterations only.
+        constexpr int NST = LN ? MI * SL : 0;
+        if (LN) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                ln_stats_issue<SL>(stat_in, stat_in_slots, M, m0 + wm * (TM / WM) + mi * 16 + frow, fq, lnt[mi]);
+        }
         int buf = 0;                               // ring slot of tile i
         int nxt = STAGES - 1;                      // ring slot the next prefetch goes to
         for (int i = 0; i < ntile; ++i) {
             const int after = min(STAGES - 2, ntile - 1 - i);      // tiles issued after tile i
-            if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
-            else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
+            if (LN && i < STAGES - 1) {
+                if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT + NST>();
+                else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT + NST>();
+                else wait_vmcnt<NST>();
+            } else {
+                if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
+                else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT>();
+                else wait_vmcnt<0>();
+            }
             __builtin_amdgcn_s_barrier();          // tile i visible to all waves; slot of tile i-1 is free
             asm volatile("" ::: "memory");
             if (i + STAGES - 1 < ntile) stage(nxt, kt_begin + i + STAGES - 1);
@@ -185,19 +208,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     }
 
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
+    float* const statlds = (float*)(smem + STAGES * STAGE);        // [WN][TM][2] scratch behind the ring
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
-        if (m >= M) continue;
+        const bool mok = m < M;
+        float mu = 0.f, rstd = 1.f;
+        if (LN) ln_stats_finish<SL>(lnt[mi], stat_in_slots, fq, K, ln_eps, mu, rstd);
+        float ps = 0.f, pq = 0.f;          // partial row sum / sum of squares of this lane's output columns
+        if (mok) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
-            if (n >= N) continue;
-            if (splitk > 1) {
-                *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
-            } else {
-                epilogue_store(epi, m, n, acc[ni][mi]);
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+                if (n >= N) continue;
+                if (splitk > 1) {
+                    *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
+                } else {
+                    const f32x4 v0 = LN ? ln_correct(ln_s, n, acc[ni][mi], mu, rstd) : acc[ni][mi];
+                    const f32x4 r = epilogue_write(epi, m, n, epilogue_value(epi, m, n, v0));
+                    ps += (r[0] + r[1]) + (r[2] + r[3]);
+                    pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                }
             }
+        }
+        if (stat_out && splitk == 1) {     // (uniform branch) per-row partial of this wave's columns -> LDS
+            ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+            pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
+            const int lr = wm * (TM / WM) + mi * 16 + frow;
+            if (fq == 0) { statlds[(wn * TM + lr) * 2] = ps; statlds[(wn * TM + lr) * 2 + 1] = pq; }
+        }
+    }
+    if (stat_out && splitk == 1) {         // one slot per column tile: wave columns summed in a fixed order
+        __syncthreads();
+        for (int lr = tid; lr < TM; lr += 64 * NW) {
+            const int m = m0 + lr;
+            if (m >= M) continue;
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int c = 0; c < WN; ++c) { a += statlds[(c * TM + lr) * 2]; q += statlds[(c * TM + lr) * 2 + 1]; }
+            *(float2*)(stat_out + ((size_t)blockIdx.y * M + m) * 2) = float2{a, q};
         }
     }
 }
@@ -206,20 +255,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) {
     const int n = (blockIdx.x * 64 + (threadIdx.x & 63)) << 2;
     const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (n >= p.N || m >= p.M) return;
-    const size_t slab = (size_t)p.M * p.N;
-    const float* src = p.ws + (size_t)m * p.N + n;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    int z = 0;
-    for (; z + 4 <= p.splitk; z += 4) {
-        const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
-        const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
-        const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
-        const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
-        v += (a + b) + (c + d);
+    const bool ok = n < p.N && m < p.M;
+    float ps = 0.f, pq = 0.f;
+    if (ok) {
+        const size_t slab = (size_t)p.M * p.N;
+        const float* src = p.ws + (size_t)m * p.N + n;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= p.splitk; z += 4) {
+            const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
+            const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
+            const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
+            const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
+            v += (a + b) + (c + d);
+        }
+        for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
+        const Epilogue e = make_epilogue(p);
+        const f32x4 r = epilogue_write(e, m, n, epilogue_value(e, m, n, v));
+        ps = (r[0] + r[1]) + (r[2] + r[3]);
+        pq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
     }
-    for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
-    epilogue_store(make_epilogue(p), m, n, v);
+    if (p.stat_out) {                      // one slot per 256-column chunk (= blockIdx.x); the wave owns one row
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+        if ((threadIdx.x & 63) == 0 && m < p.M) *(float2*)(p.stat_out + ((size_t)blockIdx.x * p.M + m) * 2) = float2{ps, pq};
+    }
 }
 
 }  // namespace
@@ -317,6 +377,11 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
 
 int gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).splitk; }
 int gemm_max_splitk() { return 32; }
+int gemm_stat_slots(int M, int N, int K) {
+    const GemmPlan g = gemm_plan(M, N, K, 0);
+    if (g.splitk > 1) return (N + 255) / 256;
+    return (N + kTileN[g.cfg] - 1) / kTileN[g.cfg];            // one slot per column tile
+}
 int gemm_tile_index(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).cfg; }
 
 size_t gemm_ws_bytes(int M, int N, int splitk) {
@@ -325,7 +390,7 @@ size_t gemm_ws_bytes(int M, int N, int splitk) {
 
 template <int TM, int TN, int WM, int WN, int STAGES>
 static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
-    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128);
+    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (size_t)WN * TM * 2 * sizeof(float);
     static bool attr_set[2] = {false, false};
     if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
         hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -335,7 +400,19 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
     }
     dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
     dim3 block(64 * WM * WN);
-    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
+    if (a.ln_s) {
+        static bool ln_attr = false;
+        if (lds > 64 * 1024 && !ln_attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+            ln_attr = true;
+        }
+        if (a.stat_in_slots <= 4) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 1>), grid, block, lds, stream, a);
+        else if (a.stat_in_slots <= 12) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 3>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 5>), grid, block, lds, stream, a);
+    } else if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
     else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, a);
     return 0;
 }
@@ -350,7 +427,15 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.act == 2 && (a.out_f32 || a.R)) return mkd_fail(-1, "gemm: GEGLU epilogue takes no residual and writes bf16");
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
+    if (a.ln_s && (a.conv || a.K > 8192)) return mkd_fail(-1, "gemm: fused LayerNorm is for linear GEMMs");
     GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+    if (a.ln_s && (!a.stat_in || a.stat_in_slots <= 0 || a.stat_in_slots > 20))
+        return mkd_fail(-1, "gemm: fused LayerNorm needs the producer's row statistics in 1..20 column slots");
+    if (a.ln_s && g.splitk > 1) {          // the LN correction is applied on the full-K accumulator
+        g.splitk = 1;
+        g.per = (a.K + BK - 1) / BK;
+    }
+    if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
     if (g.cfg >= N_GATHER_CFG) {
         if (conv_patch_supported(a, g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
         if (g_force_cfg >= N_GATHER_CFG) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");

@@ -300,6 +300,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
 }
 
+// LayerNorm folding (load time): W'[n][k] = bf16(W[n][k] * gamma[k]) written to row dst_row0 + n * dst_row_mul,
+// s[n] = sum_k float(W'[n][k]) (of the ROUNDED values the MFMA will see), b'[n] = bias[n] + sum_k W[n][k] * beta[k].
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             int N, int K, bf16_t* __restrict__ w_out, int dst_row0,
+                                                             int dst_row_mul, float* __restrict__ s_out, float* __restrict__ b_out) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    const int dr = dst_row0 + n * dst_row_mul;
+    float s = 0.f, bb = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wv = w[(size_t)n * K + k];
+        const uint16_t r = f32_to_bf16(wv * gamma[k]);
+        w_out[(size_t)dr * K + k] = r;
+        s += bf16_to_f32(r);
+        bb += wv * beta[k];
+    }
+    s = wave_sum(s); bb = wave_sum(bb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_out[dr] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        b_out[dr] = (bias ? bias[n] : 0.f) + red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
 int gn_chunks(int hw) {
     int n = hw / 16;              // >= 16 pixels per chunk
     if (n < 1) n = 1;
@@ -381,5 +407,13 @@ int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, flo
     else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
     else return mkd_fail(-4, "layernorm: d > 2048 unsupported");
     MKD_LAUNCH_CHECK("layernorm_kernel");
+    return 0;
+}
+
+int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
+                          bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_layernorm_kernel, dim3(N), dim3(256), 0, stream, w, gamma, beta, bias, N, K, w_out, dst_row0,
+                       dst_row_mul, s_out, b_out);
+    MKD_LAUNCH_CHECK("fold_layernorm_kernel");
     return 0;
 }

@@ -8,6 +8,7 @@ typedef uint16_t bf16_t;   // raw bf16 bits on the host side of the launchers
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void mkd_set_error(const std::string& msg);
@@ -61,6 +62,9 @@ struct GemmArgs {
     int conv; int Hin, Win, Cin, Hout, Wout, stride, up;
     float* ws; int splitk; int ksteps_per_split;
     int tile_h, tile_w, tile_imgs;          // spatial tile of the LDS-staged conv kernel (set by its launcher)
+    const float* ln_s; float ln_eps;        // fused LayerNorm on the A rows: ln_s[n] = sum_k W'[n][k] (W' = W*gamma), else null
+    const float* stat_in; int stat_in_slots; // ... whose row sums were emitted by the producer: [slots][M][2] (sum, sumsq)
+    float* stat_out;                        // producer side: emit per-column-slot partial row sums of the (rounded) output
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
@@ -76,6 +80,7 @@ struct StepState {
 // launchers (each only enqueues on `stream`)
 int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
+int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
 int  gemm_num_tile_cfgs();
@@ -89,6 +94,8 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
                      hipStream_t stream);
 size_t groupnorm_partials_bytes(int batch, int hw, int groups);
+int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
+                          bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream);
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
                      int rows, int d, hipStream_t stream);
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,

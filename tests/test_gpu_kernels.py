@@ -64,6 +64,48 @@ def test_gemm_fused_geglu():
         assert_close_bf16(out, ref, what='fused geglu')
 
 
+@pytest.mark.parametrize('M,d,N2,cfg', [(300, 320, 960, -1), (128, 1280, 1280, -1), (2048, 640, 1920, -1), (512, 320, 320, 3),
+                                         (100, 64, 128, 5), (8192, 320, 2560, -1), (512, 1280, 3840, -1)])
+def test_gemm_fused_layernorm_chain(M, d, N2, cfg):
+    """h = A.W1^T + b1 + R (producer GEMM emits partial row sums of the rounded h), then LN(h).W2^T + b2 through the
+    folded-weight GEMM whose epilogue applies rstd*(acc - mu*rowsum(W2')) -- vs torch linear -> layer_norm -> linear.
+    Rows get a large common offset so the mean-subtraction path is really exercised."""
+    lib = L()
+    g = torch.Generator().manual_seed(M + d + N2)
+    A = bf(torch.randn(M, d, generator=g)); W1 = bf(torch.randn(d, d, generator=g) / math.sqrt(d))
+    b1 = torch.randn(d, generator=g).to(DEV)
+    R = bf(torch.randn(M, d, generator=g) + torch.randn(M, 1, generator=g) * 2.0)
+    h = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    stats = torch.full((64, M, 2), float('nan'), device=DEV)
+    slots = C.c_int(0)
+    rc = lib.mkd_gemm_rowstats_bf16(P(A), d, P(W1), d, P(b1), P(R), d, P(h), d, M, d, d, P(stats), 64, C.byref(slots), None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    href = A.float() @ W1.float().t() + b1 + R.float()
+    assert_close_bf16(h, href, what='producer gemm')
+    st = stats[:slots.value].sum(0)
+    assert torch.isfinite(st).all()
+    assert torch.allclose(st[:, 0], h.float().sum(1), rtol=1e-4, atol=1e-2), 'row sums'
+    assert torch.allclose(st[:, 1], (h.float() ** 2).sum(1), rtol=1e-4, atol=1e-2), 'row sums of squares'
+    W2 = (torch.randn(N2, d, generator=g) / math.sqrt(d)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV); beta = (0.2 * torch.randn(d, generator=g)).to(DEV)
+    b2 = torch.randn(N2, generator=g).to(DEV)
+    Wf = torch.empty(N2, d, device=DEV, dtype=torch.bfloat16); s = torch.empty(N2, device=DEV); bfold = torch.empty(N2, device=DEV)
+    assert lib.mkd_fold_layernorm(P(W2), P(gamma), P(beta), P(b2), N2, d, P(Wf), 0, 1, P(s), P(bfold), None) == 0
+    out = torch.zeros(M, N2, device=DEV, dtype=torch.bfloat16)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        rc = lib.mkd_gemm_ln_bf16(P(h), d, P(Wf), d, P(bfold), P(s), P(stats), slots.value, 1e-5, 0, P(out), N2, M, N2, d, None)
+        assert rc == 0, lib.mkd_last_error()
+        sync()
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    ref = F.linear(F.layer_norm(h.float(), (d,), gamma, beta, 1e-5), W2, b2)
+    # the A operand is the raw row (bf16) instead of the normalised row rounded to bf16: same input precision, but
+    # the rounding is relative to |h| not |h - mean| -> allow 2x the generic kernel budget
+    assert_close_bf16(out, ref, rel=8e-3, what='fused layernorm gemm')
+
+
 def test_gemm_epilogue_variants():
     g = torch.Generator().manual_seed(7)
     M, N, K, rpb = 512, 640, 640, 128

@@ -188,3 +188,23 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         mdist.shard_range(8, 2, 2)
+
+
+# ---- generated code hygiene (no GPU needed: hipcc cross-compiles) ------------------------------------------------------
+@pytest.mark.timeout(600)
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """A by-value argument block that escapes to the stack silently costs 1.3-1.9x (seen once): every MFMA kernel must
+    compile to private_segment_fixed_size 0 and without VGPR spills."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    csrc = os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc')
+    for src in ('kernels_gemm.hip', 'kernels_conv.hip', 'kernels_attn.hip', 'kernels_norm.hip'):
+        out = tmp_path / (src + '.s')
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-I', csrc, '-S',
+                               '--cuda-device-only', os.path.join(csrc, src), '-o', str(out)], stderr=subprocess.DEVNULL)
+        txt = out.read_text()
+        sizes = re.findall(r'^\s+\.private_segment_fixed_size:\s+(\d+)', txt, flags=re.M)
+        spills = re.findall(r'^\s+\.vgpr_spill_count:\s+(\d+)', txt, flags=re.M)
+        assert sizes and all(int(v) == 0 for v in sizes), (src, sizes)
+        assert all(int(v) == 0 for v in spills), (src, spills)
