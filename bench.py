@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from makeupdiffuse_amd import dist as mdist  # noqa: E402
-from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
+from makeupdiffuse_amd.engine import MkdEngine, NetConfig, VaeConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
 def log(msg):
@@ -83,6 +83,8 @@ def gen_weights(eng, seed, keep_cpu):
         if keep_cpu:
             cpu[name] = t.cpu()
     eng.finalize()
+    if eng.vae_cfg is not None:
+        eng.finalize_vae()
     return cpu
 
 
@@ -121,7 +123,8 @@ def main():
     ap.add_argument('--cfg', action='store_true', help='classifier-free guidance 9.0 (2 evals / step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-evals', type=int, default=2)
-    ap.add_argument('--graph', type=int, default=0)
+    ap.add_argument('--graph', type=int, default=1, help='replay the DDIM step as a hipGraph (0 = eager launches)')
+    ap.add_argument('--decode', type=int, default=1, help='1: VAE-decode the latents to images inside the timed step (images out)')
     ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
     args = ap.parse_args()
 
@@ -135,6 +138,8 @@ def main():
 
     cfg = NetConfig()
     eng = MkdEngine(cfg, dev)
+    if args.decode:
+        eng.configure_vae(VaeConfig())
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     log(f'rank {rank}/{world}: generating 1.22 G synthetic weights on {dev}')
     sd_cpu = gen_weights(eng, seed=0, keep_cpu=want_cpu)
@@ -154,7 +159,8 @@ def main():
             eng.prepare(hint, ctx)
         lat = eng.sample(x_T, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                          cfg_scale=cfg_scale, use_graph=bool(args.graph))
-        return mdist.gather_shards(lat, n_total)
+        out = eng.decode(lat) if args.decode else lat          # decode_first_stage (diffusion_makeup.py:396)
+        return mdist.gather_shards(out, n_total)
 
     for i in range(args.warmup):
         t_w = time.perf_counter()
@@ -201,12 +207,15 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'batch={B}/GPU {args.res}x{args.res}, {args.ddim_steps} DDIM steps, eta 0, '
                                    + ('CFG 9.0 (2 evals/step)' if args.cfg else 'no CFG (1 eval/step)')
-                                   + ', ControlNet+UNet every step, random-init SD-1.5 ControlNet weights, latents out',
+                                   + ', ControlNet+UNet every step, random-init SD-1.5 ControlNet weights, '
+                                   + ('VAE-decoded images out' if args.decode else 'latents out'),
                        'global_batch': n_total, 'parallelism': f'batch-shard x{world}, 1 all-gather/step'},
             'roofline': roofline,
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
-                     'launches_per_eval': eng.eps_launches(), 'device_gb': eng.device_bytes() / 1e9},
+                     'launches_per_eval': eng.eps_launches(), 'device_gb': eng.device_bytes() / 1e9,
+                     'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
+                     'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None},
             'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items()},
         }
         if want_cpu:

@@ -107,6 +107,26 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
                const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
                float cfg_scale, float* x_out, int use_graph, void* stream);
 
+/* ---- first-stage decoder ------------------------------------------------ */
+/* yaml first_stage_config.params.ddconfig (diffmodels/base_diffusion_makeup.yaml:86-107), decoder half only. */
+typedef struct mkd_vae_config {
+    int32_t z_channels;      /* 4 */
+    int32_t embed_dim;       /* 4 */
+    int32_t ch;              /* 128 */
+    int32_t n_levels;        /* 4 */
+    int32_t ch_mult[8];      /* 1,2,4,4 */
+    int32_t num_res_blocks;  /* 2 */
+    int32_t out_ch;          /* 3 */
+} mkd_vae_config;
+/* Adds the "first_stage_model.post_quant_conv.*" / "first_stage_model.decoder.*" entries to the expected state_dict
+ * (load them with mkd_load_weight).  Optional: the sampler works without it. */
+int mkd_vae_configure(mkd_ctx* ctx, const mkd_vae_config* cfg);
+int mkd_vae_finalize(mkd_ctx* ctx);
+/* Replaces decode_first_stage (diffmk/diffusion_makeup.py:396,409; diffmk/makeups.py:260-262): z / scale_factor ->
+ * post_quant_conv -> Decoder.  z [B,4,h,w] fp32 NCHW -> images [B,3,8h,8w] fp32 NCHW (unclamped, nominally [-1,1]). */
+int mkd_decode(mkd_ctx* ctx, const float* z, int batch, int h, int w, float scale_factor, float* images, void* stream);
+double mkd_decode_flops(const mkd_ctx* ctx);
+
 /* ---- introspection for bench.py ----------------------------------------------------------- */
 /* Executed matmul/conv FLOPs (2 per MAC) of one mkd_eps at the prepared shape. */
 double  mkd_eps_flops(const mkd_ctx* ctx);

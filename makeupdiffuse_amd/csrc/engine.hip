@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <string>
@@ -80,8 +81,8 @@ struct Op {
     int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
 };
 
-// kinds: [0, 12) conv GEMM by tile config, [12, 18) linear GEMM by tile config, then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 12, K_GROUPNORM = 18, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+// kinds: [0, 14) conv GEMM by tile config, [14, 28) linear GEMM by tile config, then the rest
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 14, K_GROUPNORM = 28, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
@@ -140,6 +141,15 @@ struct mkd_ctx {
     Tensor hint_emb;
     bf16_t* ctx_bf16 = nullptr;
     const float* in_hint = nullptr; const float* in_context = nullptr;
+    // ---- first-stage decoder (AutoencoderKL.decode) ----
+    bool vae_configured = false, vae_finalized = false;
+    mkd_vae_config vcfg;
+    std::map<std::string, bf16_t*> vae_fused;           // mid attention [Wq;Wk]
+    std::map<std::string, float*> vae_fused_b;
+    Arena varena; char* varena_base = nullptr; size_t varena_cap = 0;
+    std::vector<Op> plan_vae; int vae_B = 0, vae_h = 0, vae_w = 0;
+    const float* io_z = nullptr; float* io_img = nullptr; float io_inv_scale = 1.f;
+    double flops_vae = 0;
     // per-call io
     const float* io_x = nullptr; const int64_t* io_t = nullptr; float* io_out = nullptr;
     // sampler buffers
@@ -350,7 +360,7 @@ struct mkd_ctx {
         if (rc) return rc;
         if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("load_weight sync: ") + hipGetErrorString(e));
         p.loaded = true;
-        finalized = false;
+        if (p.which == 2) vae_finalized = false; else finalized = false;
         return 0;
     }
 
@@ -372,7 +382,7 @@ struct mkd_ctx {
 
     int finalize() {
         for (auto& kv : params)
-            if (!kv.second.loaded) return mkd_fail(MKD_ERR_MISSING, "weight not loaded: " + kv.first);
+            if (kv.second.which < 2 && !kv.second.loaded) return mkd_fail(MKD_ERR_MISSING, "weight not loaded: " + kv.first);
         if (finalized) return 0;
         if (!zero_page) {
             void* z = nullptr;
@@ -1104,13 +1114,221 @@ struct mkd_ctx {
         return 0;
     }
 
+    // ---------------------------------------------------------------------------------------------------------------
+    // first-stage decoder
+    // ---------------------------------------------------------------------------------------------------------------
+    static std::string vae_prefix() { return "first_stage_model."; }
+    void vae_add_res(const std::string& p, int cin, int cout) {
+        add_param(p + ".norm1.weight", {cin}, 2); add_param(p + ".norm1.bias", {cin}, 2);
+        add_param(p + ".conv1.weight", {cout, cin, 3, 3}, 2); add_param(p + ".conv1.bias", {cout}, 2);
+        add_param(p + ".norm2.weight", {cout}, 2); add_param(p + ".norm2.bias", {cout}, 2);
+        add_param(p + ".conv2.weight", {cout, cout, 3, 3}, 2); add_param(p + ".conv2.bias", {cout}, 2);
+        if (cin != cout) { add_param(p + ".nin_shortcut.weight", {cout, cin, 1, 1}, 2); add_param(p + ".nin_shortcut.bias", {cout}, 2); }
+    }
+    int vae_configure(const mkd_vae_config* c) {
+        if (vae_configured) return mkd_fail(MKD_ERR_STATE, "mkd_vae_configure: already configured");
+        if (c->n_levels < 1 || c->n_levels > 8 || c->ch % 32 || c->z_channels != c->embed_dim || c->z_channels > 8 ||
+            (c->out_ch != 3 && c->out_ch != 4))
+            return mkd_fail(MKD_ERR_UNSUPPORTED, "mkd_vae_configure: unsupported decoder configuration");
+        vcfg = *c;
+        const std::string P = vae_prefix(), D = P + "decoder.";
+        add_param(P + "post_quant_conv.weight", {c->z_channels, c->embed_dim, 1, 1}, 2);
+        add_param(P + "post_quant_conv.bias", {c->z_channels}, 2);
+        int bi = c->ch * c->ch_mult[c->n_levels - 1];
+        add_param(D + "conv_in.weight", {bi, c->z_channels, 3, 3}, 2); add_param(D + "conv_in.bias", {bi}, 2);
+        vae_add_res(D + "mid.block_1", bi, bi);
+        for (const char* n : {"q", "k", "v", "proj_out"}) {
+            add_param(D + "mid.attn_1." + n + ".weight", {bi, bi, 1, 1}, 2); add_param(D + "mid.attn_1." + n + ".bias", {bi}, 2);
+        }
+        add_param(D + "mid.attn_1.norm.weight", {bi}, 2); add_param(D + "mid.attn_1.norm.bias", {bi}, 2);
+        vae_add_res(D + "mid.block_2", bi, bi);
+        for (int lvl = c->n_levels - 1; lvl >= 0; --lvl) {
+            const int bo = c->ch * c->ch_mult[lvl];
+            for (int j = 0; j <= c->num_res_blocks; ++j) { vae_add_res(D + "up." + std::to_string(lvl) + ".block." + std::to_string(j), bi, bo); bi = bo; }
+            if (lvl != 0) {
+                add_param(D + "up." + std::to_string(lvl) + ".upsample.conv.weight", {bi, bi, 3, 3}, 2);
+                add_param(D + "up." + std::to_string(lvl) + ".upsample.conv.bias", {bi}, 2);
+            }
+        }
+        add_param(D + "norm_out.weight", {bi}, 2); add_param(D + "norm_out.bias", {bi}, 2);
+        add_param(D + "conv_out.weight", {c->out_ch, bi, 3, 3}, 2); add_param(D + "conv_out.bias", {c->out_ch}, 2);
+        vae_configured = true;
+        return 0;
+    }
+    int vae_finalize() {
+        if (!vae_configured) return mkd_fail(MKD_ERR_STATE, "decoder not configured (mkd_vae_configure)");
+        for (auto& kv : params)
+            if (kv.second.which == 2 && !kv.second.loaded) return mkd_fail(MKD_ERR_MISSING, "weight not loaded: " + kv.first);
+        if (vae_finalized) return 0;
+        if (!zero_page) {
+            void* z = nullptr;
+            int rc = dev_alloc(&z, 4096); if (rc) return rc;
+            MKD_HIP_CHECK(hipMemset(z, 0, 4096));
+            zero_page = (bf16_t*)z;
+        }
+        const std::string A = vae_prefix() + "decoder.mid.attn_1";
+        bf16_t* qk = nullptr;
+        int rc = concat_rows(&qk, {A + ".q.weight", A + ".k.weight"}); if (rc) return rc;
+        vae_fused[A] = qk;
+        const int c = (int)params.at(A + ".q.bias").numel();
+        void* b = nullptr;
+        rc = dev_alloc(&b, 2 * c * sizeof(float)); if (rc) return rc;
+        MKD_HIP_CHECK(hipMemcpy(b, params.at(A + ".q.bias").dev, c * sizeof(float), hipMemcpyDeviceToDevice));
+        MKD_HIP_CHECK(hipMemcpy((float*)b + c, params.at(A + ".k.bias").dev, c * sizeof(float), hipMemcpyDeviceToDevice));
+        vae_fused_b[A] = (float*)b;
+        MKD_HIP_CHECK(hipDeviceSynchronize());
+        vae_finalized = true;
+        return 0;
+    }
+
+    // VAE ResnetBlock: GN(eps 1e-6)+SiLU -> conv3x3 -> GN+SiLU -> conv3x3 (+ x or nin_shortcut(x))
+    void vae_resblock(const std::string& p, const Tensor& x, int cout, bf16_t* out) {
+        const size_t mk = varena.mark();
+        auto tal = [&](int C_) { Tensor t = x; t.C = C_; t.ld = C_; t.p = (bf16_t*)varena.alloc((size_t)x.rows() * C_ * sizeof(bf16_t)); return t; };
+        Tensor t1 = tal(x.C);
+        op_gn(x, wf(p + ".norm1.weight"), wf(p + ".norm1.bias"), 1e-6f, 1, t1.p, t1.ld);
+        Tensor t2 = tal(cout);
+        { Epi e; e.bias = wf(p + ".conv1.bias"); op_conv(t1, wb(p + ".conv1.weight"), cout, 1, 0, e, t2.p, t2.ld); }
+        Tensor t3 = tal(cout);
+        op_gn(t2, wf(p + ".norm2.weight"), wf(p + ".norm2.bias"), 1e-6f, 1, t3.p, t3.ld);
+        Epi e2; e2.bias = wf(p + ".conv2.bias");
+        if (x.C != cout) {
+            Tensor t4 = tal(cout);
+            Epi es; es.bias = wf(p + ".nin_shortcut.bias");
+            op_linear(x.p, x.ld, x.rows(), x.C, wb(p + ".nin_shortcut.weight"), cout, es, t4.p, t4.ld);
+            e2.R = t4.p; e2.ldr = t4.ld;
+        } else { e2.R = x.p; e2.ldr = x.ld; }
+        op_conv(t3, wb(p + ".conv2.weight"), cout, 1, 0, e2, out, cout);
+        varena.release(mk);
+    }
+
+    // single-head attention over the hw tokens of each sample, built from GEMMs (c = 512 does not fit the flash kernel)
+    void vae_attn(const std::string& p, const Tensor& x, bf16_t* out) {
+        const size_t mk = varena.mark();
+        const int c = x.C, T = x.H * x.W, M = x.rows();
+        auto buf = [&](size_t n) { return (bf16_t*)varena.alloc(n * sizeof(bf16_t)); };
+        bf16_t* g = buf((size_t)M * c);
+        op_gn(x, wf(p + ".norm.weight"), wf(p + ".norm.bias"), 1e-6f, 0, g, c);
+        bf16_t* qk = buf((size_t)M * 2 * c);
+        { Epi e; e.bias = vae_fused_b.at(p); op_linear(g, c, M, c, vae_fused.at(p), 2 * c, e, qk, 2 * c); }
+        bf16_t* vt = buf((size_t)x.B * c * T);          // V^T per sample: [c][T] = Wv . g_b^T  (v bias added after PV: softmax rows sum to 1)
+        bf16_t* sc = buf((size_t)x.B * T * T);
+        bf16_t* pr = buf((size_t)x.B * T * T);
+        bf16_t* o = buf((size_t)M * c);
+        const float scale = 1.0f / sqrtf((float)c);
+        for (int b = 0; b < x.B; ++b) {
+            { Epi e; op_linear(wb(p + ".v.weight"), c, c, c, g + (size_t)b * T * c, T, e, vt + (size_t)b * c * T, T); }
+            { Epi e; e.scale = scale;
+              GemmArgs a; memset(&a, 0, sizeof(a));
+              a.A = qk + (size_t)b * T * 2 * c; a.lda = 2 * c; a.W = qk + (size_t)b * T * 2 * c + c; a.ldw = 2 * c;
+              a.scale = scale; a.C = sc + (size_t)b * T * T; a.ldc = T; a.M = T; a.N = T; a.K = c; a.rows_per_batch = 1;
+              op_gemm(a); }
+        }
+        {
+            bf16_t* s_ = sc; bf16_t* p_ = pr; const int rows = x.B * T, cols = T;
+            push(*cur_plan, [=](hipStream_t st) { return launch_softmax_rows(s_, p_, rows, cols, st); }, 1, 0.0, K_MISC, "softmax_rows");
+        }
+        for (int b = 0; b < x.B; ++b) {
+            Epi e; e.bias = wf(p + ".v.bias");
+            op_linear(pr + (size_t)b * T * T, T, T, T, vt + (size_t)b * c * T, c, e, o + (size_t)b * T * c, c);
+        }
+        { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld; op_linear(o, c, M, c, wb(p + ".proj_out.weight"), c, e, out, c); }
+        varena.release(mk);
+    }
+
+    void build_vae_plan(int Bn, int hh, int ww) {
+        cur_plan = &plan_vae; cur_sid = 0; counting_eps = false;
+        mkd_ctx* self = this;
+        const std::string P = vae_prefix(), D = P + "decoder.";
+        const int zc = vcfg.z_channels;
+        // largest activation of the decoder: (2^(L-1) h)^2 pixels x ch*ch_mult[1 or 0] channels
+        size_t max_act = 0;
+        {
+            int bi = vcfg.ch * vcfg.ch_mult[vcfg.n_levels - 1], H = hh, W = ww;
+            max_act = (size_t)Bn * H * W * bi;
+            for (int lvl = vcfg.n_levels - 1; lvl >= 0; --lvl) {
+                const int bo = vcfg.ch * vcfg.ch_mult[lvl];
+                max_act = std::max(max_act, (size_t)Bn * H * W * std::max(bi, bo));
+                bi = bo;
+                if (lvl != 0) { H *= 2; W *= 2; max_act = std::max(max_act, (size_t)Bn * H * W * bi); }
+            }
+        }
+        bf16_t* X[2] = {(bf16_t*)varena.alloc(max_act * sizeof(bf16_t)), (bf16_t*)varena.alloc(max_act * sizeof(bf16_t))};
+        float* zq = (float*)varena.alloc((size_t)Bn * zc * hh * ww * sizeof(float));
+        {
+            const bf16_t* w_ = wb(P + "post_quant_conv.weight"); const float* b_ = wf(P + "post_quant_conv.bias");
+            const int hw = hh * ww;
+            push(*cur_plan, [self, w_, b_, zq, Bn, zc, hw](hipStream_t st) {
+                return launch_post_quant(self->io_z, w_, b_, self->io_inv_scale, zq, Bn, zc, hw, st); }, 1, 0.0, K_MISC, "post_quant");
+        }
+        int bi = vcfg.ch * vcfg.ch_mult[vcfg.n_levels - 1];
+        int cur = 0;
+        Tensor h; h.B = Bn; h.H = hh; h.W = ww; h.C = bi; h.ld = bi; h.p = X[cur];
+        {
+            const bf16_t* w_ = wb(D + "conv_in.weight"); const float* b_ = wf(D + "conv_in.bias"); bf16_t* dst = h.p;
+            push(*cur_plan, [w_, b_, zq, dst, Bn, hh, ww, zc, bi](hipStream_t st) {
+                return launch_conv3x3_direct(zq, 1, w_, b_, dst, 0, 0, nullptr, Bn, hh, ww, zc, bi, 1, st); }, 1,
+                2.0 * Bn * hh * ww * bi * 9 * zc, K_CONV_DIRECT);
+        }
+        auto step = [&](int cout) { cur ^= 1; Tensor o = h; o.C = cout; o.ld = cout; o.p = X[cur]; return o; };
+        { Tensor o = step(bi); vae_resblock(D + "mid.block_1", h, bi, o.p); h = o; }
+        { Tensor o = step(bi); vae_attn(D + "mid.attn_1", h, o.p); h = o; }
+        { Tensor o = step(bi); vae_resblock(D + "mid.block_2", h, bi, o.p); h = o; }
+        for (int lvl = vcfg.n_levels - 1; lvl >= 0; --lvl) {
+            const int bo = vcfg.ch * vcfg.ch_mult[lvl];
+            for (int j = 0; j <= vcfg.num_res_blocks; ++j) {
+                Tensor o = step(bo);
+                vae_resblock(D + "up." + std::to_string(lvl) + ".block." + std::to_string(j), h, bo, o.p);
+                h = o;
+            }
+            if (lvl != 0) {
+                Tensor o = step(h.C); o.H = h.H * 2; o.W = h.W * 2;
+                Epi e; e.bias = wf(D + "up." + std::to_string(lvl) + ".upsample.conv.bias");
+                op_conv(h, wb(D + "up." + std::to_string(lvl) + ".upsample.conv.weight"), h.C, 1, 1, e, o.p, o.ld);
+                h = o;
+            }
+        }
+        {
+            Tensor o = step(h.C);
+            op_gn(h, wf(D + "norm_out.weight"), wf(D + "norm_out.bias"), 1e-6f, 1, o.p, o.ld);
+            const bf16_t* w_ = wb(D + "conv_out.weight"); const float* b_ = wf(D + "conv_out.bias");
+            const int H2 = h.H, W2 = h.W, cin = h.C, cout = vcfg.out_ch;
+            push(*cur_plan, [self, o, w_, b_, Bn, H2, W2, cin, cout](hipStream_t st) {
+                return launch_conv3x3_direct(o.p, 0, w_, b_, self->io_img, 1, 0, nullptr, Bn, H2, W2, cin, cout, 1, st); }, 1,
+                2.0 * Bn * H2 * W2 * cout * 9 * cin, K_CONV_DIRECT);
+        }
+    }
+
+    int decode(const float* z, int Bn, int hh, int ww, float scale_factor, float* images, hipStream_t stream) {
+        if (!vae_finalized) { int rc = vae_finalize(); if (rc) return rc; }
+        if (!z || !images || Bn <= 0 || hh <= 0 || ww <= 0 || scale_factor == 0.f) return mkd_fail(MKD_ERR_ARG, "mkd_decode: bad arguments");
+        if (Bn != vae_B || hh != vae_h || ww != vae_w) {
+            // same two-pass scheme as mkd_prepare: dry run sizes the arena, second pass binds pointers
+            const size_t keep_sk = splitk_need, keep_gn = gn_need;
+            dry = true; varena.base = nullptr; varena.reset(); plan_vae.clear(); flops_vae = 0;
+            build_vae_plan(Bn, hh, ww);
+            int rc = ensure((void**)&varena_base, &varena_cap, varena.high + 256); if (rc) return rc;
+            rc = ensure((void**)&splitk_ws[0], &splitk_ws_bytes[0], std::max(splitk_need, keep_sk)); if (rc) return rc;
+            rc = ensure((void**)&gn_ws[0], &gn_ws_bytes[0], std::max(gn_need, keep_gn)); if (rc) return rc;
+            dry = false; varena.base = varena_base; varena.reset(); plan_vae.clear();
+            build_vae_plan(Bn, hh, ww);
+            for (auto& op : plan_vae) flops_vae += op.flops;
+            vae_B = Bn; vae_h = hh; vae_w = ww;
+            drop_graph();            // workspaces may have moved
+        }
+        io_z = z; io_img = images; io_inv_scale = 1.0f / scale_factor;
+        for (auto& op : plan_vae) { int rc = op.fn(stream); if (rc) return rc; }
+        return 0;
+    }
+
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
+        return weight_bytes + (int64_t)varena_cap + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
                (int64_t)(gn_ws_bytes[0] + gn_ws_bytes[1]);
     }
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
+        if (varena_base) hipFree(varena_base);
         for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
@@ -1222,6 +1440,16 @@ int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_o
     if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile: null argument");
     return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind, csv_path);
 }
+int mkd_vae_configure(mkd_ctx* ctx, const mkd_vae_config* cfg) {
+    if (!ctx || !cfg) return mkd_fail(MKD_ERR_ARG, "mkd_vae_configure: null argument");
+    return ctx->vae_configure(cfg);
+}
+int mkd_vae_finalize(mkd_ctx* ctx) { return ctx ? ctx->vae_finalize() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
+int mkd_decode(mkd_ctx* ctx, const float* z, int batch, int h, int w, float scale_factor, float* images, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->decode(z, batch, h, w, scale_factor, images, (hipStream_t)stream);
+}
+double mkd_decode_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_vae : 0.0; }
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }
 int64_t mkd_device_bytes(const mkd_ctx* ctx) { return ctx ? ctx->device_bytes() : 0; }

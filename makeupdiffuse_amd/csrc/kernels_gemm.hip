@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     constexpr int NI = TN / WN / 16;      // W fragments (16 rows) per wave
     constexpr int MI = TM / WM / 16;      // X fragments (16 rows) per wave
     static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8), "tile/wave layout");
+    static_assert(STAGES >= 2 && STAGES <= 6 && 4 * (XP + WP) + (LN ? MI * (LN > 0 ? LN : 1) : 0) < 64, "vmcnt immediates");
     constexpr int LPT = XP + WP;          // global_load_lds per wave per K-tile (exact)
 
     // hoist the argument block into registers (keeps it out of scratch)
@@ -189,14 +190,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
         int nxt = STAGES - 1;                      // ring slot the next prefetch goes to
         for (int i = 0; i < ntile; ++i) {
             const int after = min(STAGES - 2, ntile - 1 - i);      // tiles issued after tile i
-            if (LN && i < STAGES - 1) {
-                if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT + NST>();
-                else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT + NST>();
-                else wait_vmcnt<NST>();
+            const int nst = (LN && i < STAGES - 1) ? NST : 0;
+            // counted wait: N = LPT * after (+ NST); immediates only, hence the switch
+            if (nst) {
+                switch (after) {
+                    case 0: wait_vmcnt<NST>(); break;
+                    case 1: wait_vmcnt<LPT + NST>(); break;
+                    case 2: wait_vmcnt<2 * LPT + NST>(); break;
+                    case 3: wait_vmcnt<(3 * LPT + NST) & 63>(); break;
+                    default: wait_vmcnt<(4 * LPT + NST) & 63>(); break;
+                }
             } else {
-                if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
-                else if (STAGES >= 3 && after == 1) wait_vmcnt<LPT>();
-                else wait_vmcnt<0>();
+                switch (after) {
+                    case 0: wait_vmcnt<0>(); break;
+                    case 1: wait_vmcnt<LPT>(); break;
+                    case 2: wait_vmcnt<2 * LPT>(); break;
+                    case 3: wait_vmcnt<3 * LPT>(); break;
+                    default: wait_vmcnt<4 * LPT>(); break;
+                }
             }
             __builtin_amdgcn_s_barrier();          // tile i visible to all waves; slot of tile i-1 is free
             asm volatile("" ::: "memory");
@@ -292,13 +303,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 //   4: 64x128  4 waves (2x2) 3 stages   72 KiB        2 blocks/CU  43
 //   5: 64x64   4 waves (2x2) 4 stages   64 KiB        2 blocks/CU  32
 //   6..11: LDS-staged 3x3 conv tiles (kernels_conv.hip): 256x128, 256x64 (8 waves), 128x128, 128x64, 64x128, 64x64
-constexpr int N_TILE_CFG = 12;
-constexpr int N_GATHER_CFG = 6;
-static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64};
-static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64};
+//   12: 64x64 6 stages (96 KiB), 13: 64x128 5 stages (120 KiB): short-K layers, (nearly) every K-step in flight at once
+constexpr int N_TILE_CFG = 14;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
-                                                  "patch64x128", "patch64x64"};
+                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5"};
+static bool is_patch_cfg(int c) { return c >= 6 && c <= 11; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
 
@@ -329,13 +341,13 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
     if (te) {
         GemmPlan g;
         g.cfg = te->cfg;
-        const int units = te->cfg >= N_GATHER_CFG ? (K / 9) / BK : nk;     // patch conv splits over channel chunks
+        const int units = is_patch_cfg(te->cfg) ? (K / 9) / BK : nk;     // patch conv splits over channel chunks
         const int s0 = te->splitk < units ? te->splitk : units;
         g.per = (units + s0 - 1) / s0;
         g.splitk = (units + g.per - 1) / g.per;
         return g;
     }
-    if (g_force_cfg >= N_GATHER_CFG) {
+    if (is_patch_cfg(g_force_cfg)) {
         GemmPlan g;
         g.cfg = g_force_cfg;
         const int units = (K / 9) / BK > 0 ? (K / 9) / BK : 1;
@@ -436,9 +448,9 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         g.per = (a.K + BK - 1) / BK;
     }
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
-    if (g.cfg >= N_GATHER_CFG) {
+    if (is_patch_cfg(g.cfg)) {
         if (conv_patch_supported(a, g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
-        if (g_force_cfg >= N_GATHER_CFG) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
+        if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
         const int keep = g_force_cfg;                 // tuned entry from another geometry: fall back to the heuristic
         g_force_cfg = 1;
         g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0);
@@ -454,6 +466,8 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         case 2: rc = launch_tile<128, 128, 2, 2, 2>(a, g.splitk, stream); break;
         case 3: rc = launch_tile<128, 64, 2, 2, 3>(a, g.splitk, stream); break;
         case 4: rc = launch_tile<64, 128, 2, 2, 3>(a, g.splitk, stream); break;
+        case 12: rc = launch_tile<64, 64, 2, 2, 6>(a, g.splitk, stream); break;
+        case 13: rc = launch_tile<64, 128, 2, 2, 5>(a, g.splitk, stream); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
     }
     if (rc) return rc;

@@ -211,6 +211,44 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const bf16_t* __res
     }
 }
 
+// ---- row softmax over bf16 [rows, cols] (VAE mid-block attention scores), one 256-thread block per row ----------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int cols) {
+    __shared__ float red[4];
+    const bf16_t* xr = x + (size_t)blockIdx.x * cols;
+    bf16_t* yr = y + (size_t)blockIdx.x * cols;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, bf16_to_f32(xr[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(bf16_to_f32(xr[c]) - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = threadIdx.x; c < cols; c += 256) yr[c] = f32_to_bf16(__expf(bf16_to_f32(xr[c]) - mx) * inv);
+}
+
+// ---- post_quant_conv: 1x1 conv over fp32 NCHW latents with the 1/scale_factor of decode_first_stage folded in -------
+__global__ void post_quant_kernel(const float* __restrict__ z, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                  float inv_scale, float* __restrict__ out, int batch, int C, int hw) {
+    const int64_t total = (int64_t)batch * C * hw;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % hw);
+        const int co = (int)((idx / hw) % C);
+        const int b = (int)(idx / ((int64_t)hw * C));
+        float acc = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < C; ++ci) acc += bf16_to_f32(w[co * C + ci]) * (z[((size_t)b * C + ci) * hw + p] * inv_scale);
+        out[idx] = acc;
+    }
+}
+
 // ---- fp32 [Cout,Cin,kh,kw] -> bf16 [Cout][kh][kw][Cin] ----------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int kh, int kw) {
     const int64_t total = (int64_t)Cout * Cin * kh * kw;
@@ -301,10 +339,14 @@ int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const
         MKD_LAUNCH_CHECK("conv3x3_fewin_kernel");
         return 0;
     }
-    if (!in_nchw_f32 && out_nchw_f32 && Cout == 4 && stride == 1 && act == 0 && !add && Cin % 8 == 0) {
+    if (!in_nchw_f32 && out_nchw_f32 && (Cout == 4 || Cout == 3) && stride == 1 && act == 0 && !add && Cin % 8 == 0) {
         const int npix = batch * Hin * Win;
-        hipLaunchKernelGGL(conv3x3_fewout_kernel<4>, dim3((npix + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
-                           (float*)y, batch, Hin, Win, Cin);
+        if (Cout == 4)
+            hipLaunchKernelGGL(conv3x3_fewout_kernel<4>, dim3((npix + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
+                               (float*)y, batch, Hin, Win, Cin);
+        else
+            hipLaunchKernelGGL(conv3x3_fewout_kernel<3>, dim3((npix + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
+                               (float*)y, batch, Hin, Win, Cin);
         MKD_LAUNCH_CHECK("conv3x3_fewout_kernel");
         return 0;
     }
@@ -359,5 +401,19 @@ int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, flo
                            hipStream_t stream) {
     hipLaunchKernelGGL(ddim_step_state_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, cfg_scale, st, n);
     MKD_LAUNCH_CHECK("ddim_step_state_kernel");
+    return 0;
+}
+
+int launch_softmax_rows(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t stream) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, y, cols);
+    MKD_LAUNCH_CHECK("softmax_rows_kernel");
+    return 0;
+}
+
+int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float inv_scale, float* out, int batch, int C, int hw,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((int64_t)batch * C * hw)), dim3(256), 0, stream, z, w, bias, inv_scale, out,
+                       batch, C, hw);
+    MKD_LAUNCH_CHECK("post_quant_kernel");
     return 0;
 }

@@ -118,3 +118,6 @@ int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);
 int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream);
 int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, const StepState* st, int64_t n,
                            hipStream_t stream);
+int launch_softmax_rows(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t stream);
+int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float inv_scale, float* out, int batch, int C, int hw,
+                      hipStream_t stream);

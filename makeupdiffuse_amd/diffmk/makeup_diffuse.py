@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from ..ddim import DDIMSampler
-from ..engine import MkdEngine, NetConfig
+from ..engine import MkdEngine, NetConfig, VaeConfig
 from ..lib import MkdError
 from ..schedule import DDIMSchedule
 
@@ -38,6 +38,9 @@ class BaseMakeUpDiffuse:
         self.net_config = NetConfig.from_yaml_params(dict(control_stage_config.get('params', control_stage_config)),
                                                      dict(unet_config.get('params', unet_config)))
         self.first_stage_config, self.cond_stage_config = first_stage_config, cond_stage_config
+        self.vae_config = None
+        if first_stage_config is not None:
+            self.vae_config = VaeConfig.from_yaml_params(dict(first_stage_config.get('params', first_stage_config)))
         self.extra_params = dict(unused_training_params)      # w_idt_src, lambda_lip, teacher_type, ... (training only)
         self.parameterization = parameterization
         self.only_mid_control = bool(only_mid_control)
@@ -59,7 +62,6 @@ class BaseMakeUpDiffuse:
         self._bound = None
         self._cfg_cache = None
         self.cond_stage_model = None          # callable(list[str]) -> [B,77,768]; CLIP is a "next" row
-        self.first_stage_model = None         # VAE decoder, "next" row
         self.training = False
 
     # ---- nn.Module-ish surface used by runs/test.py --------------------------------------------------------
@@ -78,6 +80,8 @@ class BaseMakeUpDiffuse:
         if device.type == 'cuda':
             if self.engine is None:
                 self.engine = MkdEngine(self.net_config, device)
+                if self.vae_config is not None:
+                    self.engine.configure_vae(self.vae_config)
                 if self._pending_sd is not None:
                     self.engine.load_state_dict(self._pending_sd, strict=True)
                     self._pending_sd = None
@@ -95,7 +99,8 @@ class BaseMakeUpDiffuse:
             unused = self.engine.load_state_dict(sd, strict=strict)
         else:
             self._pending_sd = {k: v for k, v in sd.items()
-                                if k.startswith(MkdEngine.UNET_PREFIX) or k.startswith(MkdEngine.CONTROL_PREFIX)}
+                                if k.startswith(MkdEngine.UNET_PREFIX) or k.startswith(MkdEngine.CONTROL_PREFIX)
+                                or k.startswith('first_stage_model.post_quant_conv.') or k.startswith('first_stage_model.decoder.')}
             unused = [k for k in sd if k not in self._pending_sd]
         return [], unused
 
@@ -221,9 +226,15 @@ class BaseMakeUpDiffuse:
         return sampler.sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
 
     def decode_first_stage(self, z: torch.Tensor) -> torch.Tensor:
-        if self.first_stage_model is None:
-            raise NotImplementedError('VAE decoder (first_stage_config) is the next row after the sampler (SURVEY.md §8f rank 1)')
-        return self.first_stage_model.decode(z / self.scale_factor)
+        """z / scale_factor -> post_quant_conv -> Decoder (UPSTREAM AutoencoderKL.decode), on the device via mkd_decode."""
+        eng = self._require_engine()
+        if eng.vae_cfg is None:
+            raise NotImplementedError('no first_stage_config in the yaml: the decoder was not configured')
+        return eng.decode(z, self.scale_factor)
+
+    @property
+    def has_first_stage(self) -> bool:
+        return self.engine is not None and self.engine.vae_cfg is not None
 
 
 class TestDiffuseModel(BaseMakeUpDiffuse):
@@ -260,7 +271,7 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
             samples, _ = self.sample_log(cond=cond, batch_size=b, ddim=use_ddim, ddim_steps=self.ddim_steps,
                                          eta=self.ddim_eta, **extra)
             log['samples_latent'] = samples
-            if self.first_stage_model is not None:
+            if self.has_first_stage:
                 log['samples'] = self.decode_first_stage(samples)
         if self.unconditional_guidance_scale > 1.0:
             uc_full = {'c_concat': [c_cat], 'c_crossattn': [self.get_unconditional_conditioning(b)]}
@@ -269,7 +280,7 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
                                              unconditional_conditioning=uc_full, **extra)
             name = f'samples_cfg_scale_{self.unconditional_guidance_scale:.2f}'
             log[name + '_latent'] = samples_cfg
-            if self.first_stage_model is not None:
+            if self.has_first_stage:
                 log[name] = self.decode_first_stage(samples_cfg)
         return log
 

@@ -69,6 +69,34 @@ class NetConfig:
         return n + 1
 
 
+@dataclass
+class VaeConfig:
+    """first_stage_config.params.ddconfig of diffmodels/base_diffusion_makeup.yaml:86-107 (decoder half)."""
+    z_channels: int = 4
+    embed_dim: int = 4
+    ch: int = 128
+    ch_mult: Sequence[int] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    out_ch: int = 3
+
+    @classmethod
+    def from_yaml_params(cls, first_stage_params: dict) -> 'VaeConfig':
+        dd = first_stage_params.get('ddconfig', first_stage_params)
+        if dd.get('attn_resolutions'):
+            raise NotImplementedError('decoder attention resolutions other than the mid block are not supported')
+        return cls(z_channels=dd.get('z_channels', 4), embed_dim=first_stage_params.get('embed_dim', 4), ch=dd.get('ch', 128),
+                   ch_mult=tuple(dd.get('ch_mult', (1, 2, 4, 4))), num_res_blocks=dd.get('num_res_blocks', 2),
+                   out_ch=dd.get('out_ch', 3))
+
+    def to_c(self) -> _lib.VaeConfigC:
+        c = _lib.VaeConfigC()
+        c.z_channels, c.embed_dim, c.ch, c.n_levels = self.z_channels, self.embed_dim, self.ch, len(self.ch_mult)
+        for i, m in enumerate(self.ch_mult):
+            c.ch_mult[i] = m
+        c.num_res_blocks, c.out_ch = self.num_res_blocks, self.out_ch
+        return c
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -97,6 +125,7 @@ class MkdEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mkd_ctx_create(C.byref(cfg.to_c()), C.byref(self._ctx)), 'mkd_ctx_create')
         self._keep: list = []          # tensors the prepared plan points at
+        self.vae_cfg: Optional[VaeConfig] = None
         self._prepared_key = None
         self.batch = 0
         self.latent_hw: Tuple[int, int] = (0, 0)
@@ -148,10 +177,13 @@ class MkdEngine:
             else:
                 unused.append(k)
         missing = [k for k in expected if k not in sd]
-        if missing and strict:
-            raise _lib.MkdError(f'{len(missing)} weights missing from state_dict, e.g. {missing[:3]}')
-        if not missing:
+        core_missing = [k for k in missing if not k.startswith('first_stage_model.')]
+        if core_missing and strict:
+            raise _lib.MkdError(f'{len(core_missing)} weights missing from state_dict, e.g. {core_missing[:3]}')
+        if not core_missing:
             self.finalize()
+        if getattr(self, 'vae_cfg', None) is not None and not [k for k in missing if k.startswith('first_stage_model.')]:
+            self.finalize_vae()
         return unused
 
     def init_random(self, seed: int = 0, gain: float = 1.0) -> None:
@@ -176,6 +208,31 @@ class MkdEngine:
     def finalize(self) -> None:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mkd_weights_finalize(self._ctx), 'mkd_weights_finalize')
+
+    # ---- first-stage decoder -------------------------------------------------------------------------
+    def configure_vae(self, vcfg: VaeConfig) -> None:
+        """Adds the first_stage_model.{post_quant_conv,decoder}.* entries to expected_params(); load them like the rest."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_vae_configure(self._ctx, C.byref(vcfg.to_c())), 'mkd_vae_configure')
+        self.vae_cfg = vcfg
+
+    def finalize_vae(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_vae_finalize(self._ctx), 'mkd_vae_finalize')
+
+    def decode(self, z: torch.Tensor, scale_factor: float = 0.18215) -> torch.Tensor:
+        """decode_first_stage: z [B,4,h,w] -> images [B,3,8h,8w] fp32 (unclamped)."""
+        z = _f32c(z, self.device)
+        B, _, h, w = z.shape
+        up = 2 ** (len(self.vae_cfg.ch_mult) - 1)
+        out = torch.empty((B, self.vae_cfg.out_ch, h * up, w * up), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_decode(self._ctx, C.c_void_p(z.data_ptr()), B, h, w, float(scale_factor),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), 'mkd_decode')
+        return out
+
+    def decode_flops(self) -> float:
+        return float(self.lib.mkd_decode_flops(self._ctx))
 
     # ---- conditioning / eval -----------------------------------------------------------------------
     def prepare(self, hint: Optional[torch.Tensor], context: torch.Tensor, latent_hw: Optional[Tuple[int, int]] = None,

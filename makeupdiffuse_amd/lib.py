@@ -16,6 +16,11 @@ class MkdError(RuntimeError):
     pass
 
 
+class VaeConfigC(C.Structure):
+    _fields_ = [('z_channels', C.c_int32), ('embed_dim', C.c_int32), ('ch', C.c_int32), ('n_levels', C.c_int32),
+                ('ch_mult', C.c_int32 * 8), ('num_res_blocks', C.c_int32), ('out_ch', C.c_int32)]
+
+
 class NetConfigC(C.Structure):
     _fields_ = [
         ('in_channels', C.c_int32), ('out_channels', C.c_int32), ('hint_channels', C.c_int32),
@@ -47,6 +52,10 @@ SIGNATURES = {
     'mkd_eps': (_I, [_P, _P, _P, _P, _P]),
     'mkd_ddim_step': (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _P, _L, _P]),
     'mkd_sample': (_I, [_P, _P, _I, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _P, _I, _P]),
+    'mkd_vae_configure': (_I, [_P, C.POINTER(VaeConfigC)]),
+    'mkd_vae_finalize': (_I, [_P]),
+    'mkd_decode': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
+    'mkd_decode_flops': (C.c_double, [_P]),
     'mkd_kind_count': (_I, []),
     'mkd_kind_name': (C.c_char_p, [_I]),
     'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.c_char_p]),

@@ -103,6 +103,51 @@ def test_small_sample_loop(small):
     assert torch.allclose(outg, out, rtol=1e-5, atol=1e-6), (outg - out).abs().max()
 
 
+VSMALL = dict(z_channels=4, embed_dim=4, ch=32, ch_mult=(1, 2), num_res_blocks=1, out_ch=3)
+
+
+def test_vae_decode_small_vs_oracle():
+    from makeupdiffuse_amd.engine import VaeConfig
+    from oracle import vae
+    ocfg = vae.VaeConfig(**VSMALL)
+    sd = vae.init_state_dict(ocfg, seed=5)
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.configure_vae(VaeConfig(**VSMALL))
+    exp = {k for k in eng.expected_params() if k.startswith('first_stage_model.')}
+    assert exp == set(sd), exp ^ set(sd)
+    for k, v in sd.items():
+        eng.load_weight(k, v)
+    eng.finalize_vae()
+    gen = torch.Generator().manual_seed(2)
+    for (B, h, w) in [(2, 8, 8), (3, 4, 12)]:
+        z = torch.randn(B, 4, h, w, generator=gen) * 0.18215
+        ref = vae.decode_first_stage(sd, ocfg, z)
+        out = eng.decode(z)
+        assert out.shape == ref.shape == (B, 3, 2 * h, 2 * w)
+        check_eps(out, ref, rel=1.5e-2, cos=0.9997, what=f'vae decode {B}x{h}x{w}')
+    eng.close()
+
+
+@pytest.mark.timeout(600)
+def test_vae_decode_full_size_vs_oracle():
+    """SD-1.x decoder of the yaml (49.49 M params), one 32x32 latent -> 256x256 image, vs the fp32 CPU oracle."""
+    from makeupdiffuse_amd.engine import VaeConfig
+    from oracle import vae
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    sd = vae.init_state_dict(vae.FULL, seed=0)
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.configure_vae(VaeConfig())
+    for k, v in sd.items():
+        eng.load_weight(k, v)
+    eng.finalize_vae()
+    z = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(3)) * 0.18215
+    ref = vae.decode_first_stage(sd, vae.FULL, z)
+    out = eng.decode(z)
+    r, c = check_eps(out, ref, rel=2e-2, cos=0.9995, what='full-size vae decode')
+    print(f'full-size vae decode: rel-L2 {r:.4e} cos {c:.6f} GFLOP {eng.decode_flops() / 1e9:.1f}')
+    eng.close()
+
+
 def test_param_counts_full():
     eng = MkdEngine(NetConfig())
     assert abs(eng.param_count('unet') / 1e6 - 859.52) < 0.01

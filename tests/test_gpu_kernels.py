@@ -46,6 +46,22 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13])
+@pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1)])
+def test_gemm_every_tile_config(cfg, M, N, K, splitk):
+    """each gather-GEMM tile / pipeline-depth configuration, incl. K not a multiple of 64 and ragged M/N."""
+    lib = L()
+    g = torch.Generator().manual_seed(cfg * 7 + M + K)
+    A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g).to(DEV)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        out = gemm(A, W, bias=bias, splitk=splitk)
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert_close_bf16(out, A.float() @ W.float().t() + bias, what=f'gemm cfg {cfg}')
+
+
 def test_gemm_fused_geglu():
     g = torch.Generator().manual_seed(11)
     for (M, inner, K, splitk) in [(512, 1280, 320, 0), (200, 640, 1280, 2)]:

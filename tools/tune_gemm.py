@@ -22,8 +22,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 
 DEV = 'cuda:0'
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128]
 POOL_BYTES = 640 << 20
 
 
@@ -97,10 +97,10 @@ def main():
         t_def = time_cfg(lib, shape, -1, 0, pool, A, out)
         best = (None, None, 1e30)
         trials = []
-        for cfg in range(12):
+        for cfg in range(14):
             if N % 128 and TILE_N[cfg] == 128 and N < 128:
                 continue
-            patch = cfg >= 6
+            patch = 6 <= cfg <= 11
             if patch and not (conv and stride == 1 and up == 0 and Cin % 64 == 0):
                 continue
             tiles = -(-M // TILE_M[cfg]) * -(-N // TILE_N[cfg])
