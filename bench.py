@@ -47,6 +47,27 @@ PEAK_HBM_GBS = 8000.0
 MFMA_PREFIXES = ('gemm_', 'attention')
 
 
+def pmc_traffic_bytes_per_launch(kernel_fn):
+    """HBM-side bytes per launch of `kernel_fn` from the committed rocprofv3 --pmc summaries (profiles/, separate passes for
+    FETCH_SIZE and WRITE_SIZE): KB -> bytes, FETCH doubled for wide streaming reads on gfx950 (MI355X_MICROARCH.md §HBM).
+    None when the summaries are absent.  (PMC cannot be collected from inside this process.)"""
+    import csv
+    tot = {}
+    for name, mult in (('r1_pmc_fetch_size_kb.csv', 2.0), ('r1_pmc_write_size_kb.csv', 1.0)):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            return None
+        n = 0; b = 0.0
+        for r in csv.DictReader(open(path)):
+            if r['kernel'].startswith(kernel_fn):
+                col = [c for c in r if c.startswith('avg_') and c != 'avg_us'][0]
+                n += int(r['dispatches']); b += int(r['dispatches']) * float(r[col]) * 1024.0 * mult
+        if n == 0:
+            return None
+        tot[name] = b / n
+    return sum(tot.values())
+
+
 def synth_inputs(lo, hi, res, ctx_dim, device):
     """SURVEY.md §8d synthetic inputs, generated PER SAMPLE so shards do not depend on the world size."""
     h = res // 8
@@ -190,14 +211,23 @@ def main():
         eng.eps_profile(x_in, tt)
         prof = eng.eps_profile(x_in, tt, csv_path=args.ops_csv)
         tot_ms = sum(v['ms'] for v in prof.values())
-        dom = max((k for k in prof if k.startswith(MFMA_PREFIXES)), key=lambda k: prof[k]['ms'])
-        d = prof[dom]
+        # kernel FUNCTIONS behind the classes: the implicit-GEMM gather kernel (all tile configs), the LDS-staged
+        # 3x3 conv kernel, the attention kernel.  The dominant one (by device time) carries the roofline.
+        fam = {'gemm_kernel': lambda k: k.startswith('gemm_') and 'patch' not in k,
+               'conv3x3_patch_kernel': lambda k: k.startswith('gemm_') and 'patch' in k,
+               'attention_kernel': lambda k: k == 'attention'}
+        agg = {f: {'ms': sum(v['ms'] for k, v in prof.items() if sel(k)), 'flops': sum(v['flops'] for k, v in prof.items() if sel(k)),
+                   'launches': sum(v['launches'] for k, v in prof.items() if sel(k))} for f, sel in fam.items()}
+        dom = max(agg, key=lambda f: agg[f]['ms'])
+        d = agg[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+        roofline = {'bound': 'mfma', 'kernel': dom + ' (all tile configurations, one eps evaluation)', 'achieved': ach,
+                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                    'traffic': pmc_traffic_bytes_per_launch(dom),
                     'launches_per_eval': d['launches'], 'avg_launch_us': 1e3 * d['ms'] / max(1, d['launches']),
                     'flops_per_launch': d['flops'] / max(1, d['launches']),
-                    'share_of_eval_time': d['ms'] / tot_ms if tot_ms else None}
+                    'share_of_eval_time': d['ms'] / tot_ms if tot_ms else None,
+                    'other_kernels_tflops': {f: (v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0) for f, v in agg.items() if f != dom}}
         loop_tflops = eps_flops * evals_per_step / (loop_ms * 1e-3) / 1e12
         result = {
             'metric': 'makeup-transfer images/sec @256x256, 50 DDIM steps' if args.res == 256 and args.ddim_steps == 50
@@ -216,7 +246,7 @@ def main():
                      'launches_per_eval': eng.eps_launches(), 'device_gb': eng.device_bytes() / 1e9,
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
                      'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None},
-            'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items()},
+            'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items() if v['ms'] > 0},
         }
         if want_cpu:
             eng.prepare(hint[:1], ctx[:1])

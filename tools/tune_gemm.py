@@ -43,6 +43,35 @@ def shapes_of(eng, batch, res):
     return out
 
 
+def vae_shapes(batch, res):
+    """GEMM / conv shapes of the first-stage decoder (ch 128, mult 1,2,4,4, 2 res blocks) for `batch` images."""
+    out = collections.Counter()
+    h = res // 8
+    ch, mult, nrb = 128, (1, 2, 4, 4), 2
+    def conv(H, cin, cout, up=0):
+        Ho = H << up
+        out[(batch * Ho * Ho, cout, 9 * cin, 1, 1, up, H, H, cin, Ho, Ho)] += 1
+    def lin(M, N, K):
+        out[(M, N, K, 0, 0, 0, 0, 0, 0, 0, 0)] += 1
+    def res_(H, cin, cout):
+        conv(H, cin, cout); conv(H, cout, cout)
+        if cin != cout:
+            lin(batch * H * H, cout, cin)
+    bi = ch * mult[-1]; H = h
+    res_(H, bi, bi); res_(H, bi, bi)
+    T = H * H
+    lin(batch * T, 2 * bi, bi); lin(batch * T, bi, bi)
+    for _ in range(batch):
+        lin(bi, T, bi); lin(T, T, bi); lin(T, bi, T)
+    for lvl in reversed(range(4)):
+        bo = ch * mult[lvl]
+        for j in range(nrb + 1):
+            res_(H, bi, bo); bi = bo
+        if lvl:
+            conv(H, bi, bi, up=1); H *= 2
+    return out
+
+
 def time_cfg(lib, shape, cfg, splitk, pool, A, out, iters=12):
     M, N, K, conv, stride, up, Hin, Win, Cin, Hout, Wout = shape
     wbytes = N * K * 2
@@ -74,15 +103,20 @@ def main():
     ap.add_argument('--batch', type=int, action='append')
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--out', default='gpurun_out/tune.json')
+    ap.add_argument('--vae', action='store_true', help='tune the first-stage decoder shapes instead of the eps plan')
     args = ap.parse_args()
     lib = mlib.load()
-    eng = MkdEngine(NetConfig())
-    eng.init_random(0)
     shapes = collections.Counter()
-    for b in (args.batch or [8]):
-        shapes.update(shapes_of(eng, b, args.res))
-    eng.close()
-    del eng
+    if args.vae:
+        for b in (args.batch or [8]):
+            shapes.update(vae_shapes(b, args.res))
+    else:
+        eng = MkdEngine(NetConfig())
+        eng.init_random(0)
+        for b in (args.batch or [8]):
+            shapes.update(shapes_of(eng, b, args.res))
+        eng.close()
+        del eng
     torch.cuda.empty_cache()
     pool = torch.randn(POOL_BYTES // 2, device=DEV, dtype=torch.bfloat16) * 0.02
     results = {}
@@ -94,7 +128,7 @@ def main():
         out = torch.empty(M * N, device=DEV, dtype=torch.bfloat16)
         nk = (K + 63) // 64
         lib.mkd_gemm_force_tile(-1)
-        t_def = time_cfg(lib, shape, -1, 0, pool, A, out)
+        t_def = time_cfg(lib, shape, -1, 0, pool, A, out, iters=6 if M * N * K > 4e11 else 12)
         best = (None, None, 1e30)
         trials = []
         for cfg in range(14):
@@ -110,7 +144,7 @@ def main():
                     continue
                 if s > 1 and s * M * N * 4 > (256 << 20):
                     continue
-                t = time_cfg(lib, shape, cfg, s, pool, A, out)
+                t = time_cfg(lib, shape, cfg, s, pool, A, out, iters=4 if M * N * K > 4e11 else 12)
                 if t is None:
                     continue
                 trials.append((cfg, s, round(t, 2)))
