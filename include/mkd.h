@@ -83,6 +83,12 @@ int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
 int mkd_prepare(mkd_ctx* ctx, int batch, int h, int w, const float* hint, const float* context,
                 const float* control_scales, int only_mid_control, void* stream);
 
+/* Makeup INTERPOLATION between two references (BUILD-DEFINED: the reference only shows a figure, README.md:23-25; SURVEY.md
+ * §8f rank 2): like mkd_prepare, but the cached ControlNet hint embedding is the per-sample blend
+ * (1 - alpha[b]) * E(hint_a[b]) + alpha[b] * E(hint_b[b]); hint_a = src||ref1, hint_b = src||ref2, alpha device fp32 [B]. */
+int mkd_prepare_interp(mkd_ctx* ctx, int batch, int h, int w, const float* hint_a, const float* hint_b, const float* alpha,
+                       const float* context, const float* control_scales, int only_mid_control, void* stream);
+
 /* ---- one eps evaluation ----------------------------------------------------------------- */
 /* Replaces apply_model (makeup_diffuse.py:152-170): ControlNet -> 13 residuals x scale ->
  * ControlledUnet.  x [B,4,h,w] fp32 NCHW, t [B] int64 (device), eps_out [B,4,h,w] fp32. */

@@ -141,6 +141,7 @@ struct mkd_ctx {
     Tensor hint_emb;
     bf16_t* ctx_bf16 = nullptr;
     const float* in_hint = nullptr; const float* in_context = nullptr;
+    const float* in_hint2 = nullptr; const float* in_alpha = nullptr; bool has_interp = false;   // makeup interpolation (build-defined)
     // ---- first-stage decoder (AutoencoderKL.decode) ----
     bool vae_configured = false, vae_finalized = false;
     mkd_vae_config vcfg;
@@ -755,25 +756,38 @@ struct mkd_ctx {
             for (int j = 0; j < 7; ++j) widths[j + 1] = cfg.hint_widths[j];
             widths[8] = cfg.model_channels;
             const int H0 = 8 * h, W0 = 8 * w;
-            const size_t mk = TA().mark();
-            Tensor cur = talloc(TA(), B, H0, W0, widths[1]);
-            {
-                const bf16_t* wgt = wb(P + "input_hint_block.0.weight"); const float* bias = wf(P + "input_hint_block.0.bias");
-                const int Bn = B, cin = widths[0], cout = widths[1];
-                push(*cur_plan, [self, wgt, bias, cur, Bn, H0, W0, cin, cout](hipStream_t st) {
-                    return launch_conv3x3_direct(self->in_hint, 1, wgt, bias, cur.p, 0, 1, nullptr, Bn, H0, W0, cin, cout, 1, st);
+            // input_hint_block on hint (which == 0) or on the second reference's hint (which == 1, interpolation)
+            auto hint_chain = [&](int which2) -> Tensor {
+                const size_t mk = TA().mark();
+                Tensor cur = talloc(TA(), B, H0, W0, widths[1]);
+                {
+                    const bf16_t* wgt = wb(P + "input_hint_block.0.weight"); const float* bias = wf(P + "input_hint_block.0.bias");
+                    const int Bn = B, cin = widths[0], cout = widths[1];
+                    push(*cur_plan, [self, wgt, bias, cur, Bn, H0, W0, cin, cout, which2](hipStream_t st) {
+                        return launch_conv3x3_direct(which2 ? self->in_hint2 : self->in_hint, 1, wgt, bias, cur.p, 0, 1, nullptr, Bn, H0,
+                                                     W0, cin, cout, 1, st);
+                    }, 1, 0.0);
+                }
+                for (int j = 1; j < 8; ++j) {
+                    const int s = strides[j];
+                    const int Ho = (cur.H - 1) / s + 1, Wo = (cur.W - 1) / s + 1;
+                    Tensor nxt = (j == 7) ? talloc(persist, B, Ho, Wo, widths[j + 1]) : talloc(TA(), B, Ho, Wo, widths[j + 1]);
+                    Epi e; e.bias = wf(P + "input_hint_block." + std::to_string(2 * j) + ".bias"); e.act = (j == 7) ? 0 : 1;
+                    op_conv(cur, wb(P + "input_hint_block." + std::to_string(2 * j) + ".weight"), widths[j + 1], s, 0, e, nxt.p, nxt.ld);
+                    cur = nxt;
+                }
+                TA().release(mk);
+                return cur;
+            };
+            hint_emb = hint_chain(0);
+            if (has_interp) {
+                Tensor e2 = hint_chain(1);
+                Tensor he = hint_emb; const int Bn = B;
+                const int64_t per = (int64_t)he.H * he.W * he.C;
+                push(*cur_plan, [self, he, e2, per, Bn](hipStream_t st) {
+                    return launch_blend(he.p, e2.p, self->in_alpha, he.p, per, Bn, st);
                 }, 1, 0.0);
             }
-            for (int j = 1; j < 8; ++j) {
-                const int s = strides[j];
-                const int Ho = (cur.H - 1) / s + 1, Wo = (cur.W - 1) / s + 1;
-                Tensor nxt = (j == 7) ? talloc(persist, B, Ho, Wo, widths[j + 1]) : talloc(TA(), B, Ho, Wo, widths[j + 1]);
-                Epi e; e.bias = wf(P + "input_hint_block." + std::to_string(2 * j) + ".bias"); e.act = (j == 7) ? 0 : 1;
-                op_conv(cur, wb(P + "input_hint_block." + std::to_string(2 * j) + ".weight"), widths[j + 1], s, 0, e, nxt.p, nxt.ld);
-                cur = nxt;
-            }
-            hint_emb = cur;
-            TA().release(mk);
         }
     }
 
@@ -907,18 +921,21 @@ struct mkd_ctx {
     }
 
     int prepare(int batch, int hh, int ww, const float* hint, const float* context, const float* control_scales,
-                int only_mid_control, hipStream_t stream) {
+                int only_mid_control, hipStream_t stream, const float* hint2 = nullptr, const float* alpha = nullptr) {
         if (!finalized) return mkd_fail(MKD_ERR_STATE, "mkd_prepare before mkd_weights_finalize");
         if (batch <= 0 || hh <= 0 || ww <= 0 || !context) return mkd_fail(MKD_ERR_ARG, "mkd_prepare: bad arguments");
         const int down = 1 << (cfg.n_levels - 1);
         if (hh % down || ww % down) return mkd_fail(MKD_ERR_ARG, "mkd_prepare: latent h, w must be multiples of " + std::to_string(down));
         const bool ctrl = hint != nullptr;
-        const bool same = prepared && batch == B && hh == h && ww == w && ctrl == has_control && (only_mid_control != 0) == only_mid;
+        const bool interp = hint2 != nullptr;
+        if (interp && (!ctrl || !alpha)) return mkd_fail(MKD_ERR_ARG, "mkd_prepare_interp: needs hint, hint2 and alpha");
+        const bool same = prepared && batch == B && hh == h && ww == w && ctrl == has_control && (only_mid_control != 0) == only_mid &&
+                          interp == has_interp;
         bool same_scales = same;
         for (int i = 0; i < n_ctrl() && same_scales; ++i) same_scales = scales[i] == (control_scales ? control_scales[i] : 1.f);
-        in_hint = hint; in_context = context;
+        in_hint = hint; in_context = context; in_hint2 = hint2; in_alpha = alpha;
         if (!same_scales) {
-            B = batch; h = hh; w = ww; has_control = ctrl; only_mid = only_mid_control != 0;
+            B = batch; h = hh; w = ww; has_control = ctrl; only_mid = only_mid_control != 0; has_interp = interp;
             for (int i = 0; i < n_ctrl(); ++i) scales[i] = control_scales ? control_scales[i] : 1.f;
             prepared = false;
             // pass 1: dry run to size the arenas (pointers are offsets from null and never dereferenced)
@@ -1408,6 +1425,12 @@ int mkd_prepare(mkd_ctx* ctx, int batch, int h, int w, const float* hint, const 
                 const float* control_scales, int only_mid_control, void* stream) {
     if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
     return ctx->prepare(batch, h, w, hint, context, control_scales, only_mid_control, (hipStream_t)stream);
+}
+int mkd_prepare_interp(mkd_ctx* ctx, int batch, int h, int w, const float* hint_a, const float* hint_b, const float* alpha,
+                       const float* context, const float* control_scales, int only_mid_control, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    if (!hint_a || !hint_b || !alpha) return mkd_fail(MKD_ERR_ARG, "mkd_prepare_interp: null pointer");
+    return ctx->prepare(batch, h, w, hint_a, context, control_scales, only_mid_control, (hipStream_t)stream, hint_b, alpha);
 }
 int mkd_eps(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream) {
     if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");

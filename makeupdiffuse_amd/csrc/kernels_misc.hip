@@ -249,6 +249,21 @@ __global__ void post_quant_kernel(const float* __restrict__ z, const bf16_t* __r
     }
 }
 
+// ---- per-sample blend of two bf16 tensors: y = (1 - alpha[b]) * a + alpha[b] * b (makeup interpolation) ---------------
+__global__ void blend_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ alpha,
+                             bf16_t* __restrict__ y, int64_t per_sample, int batch) {
+    const int64_t total = per_sample * batch / 8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const float al = alpha[(idx * 8) / per_sample];
+        const U16x8 va = *(const U16x8*)(a + idx * 8);
+        const U16x8 vb = *(const U16x8*)(b + idx * 8);
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = f32_to_bf16((1.0f - al) * bf16_to_f32(va.v[j]) + al * bf16_to_f32(vb.v[j]));
+        *(U16x8*)(y + idx * 8) = o;
+    }
+}
+
 // ---- fp32 [Cout,Cin,kh,kw] -> bf16 [Cout][kh][kw][Cin] ----------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int kh, int kw) {
     const int64_t total = (int64_t)Cout * Cin * kh * kw;
@@ -415,5 +430,12 @@ int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float 
     hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((int64_t)batch * C * hw)), dim3(256), 0, stream, z, w, bias, inv_scale, out,
                        batch, C, hw);
     MKD_LAUNCH_CHECK("post_quant_kernel");
+    return 0;
+}
+
+int launch_blend(const bf16_t* a, const bf16_t* b, const float* alpha, bf16_t* y, int64_t per_sample, int batch, hipStream_t stream) {
+    if (per_sample % 8) return mkd_fail(-1, "blend: per-sample size must be a multiple of 8");
+    hipLaunchKernelGGL(blend_kernel, dim3(grid_for(per_sample * batch / 8)), dim3(256), 0, stream, a, b, alpha, y, per_sample, batch);
+    MKD_LAUNCH_CHECK("blend_kernel");
     return 0;
 }

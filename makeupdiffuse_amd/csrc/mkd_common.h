@@ -121,3 +121,4 @@ int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, flo
 int launch_softmax_rows(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t stream);
 int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float inv_scale, float* out, int batch, int C, int hw,
                       hipStream_t stream);
+int launch_blend(const bf16_t* a, const bf16_t* b, const float* alpha, bf16_t* y, int64_t per_sample, int batch, hipStream_t stream);

@@ -284,6 +284,43 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
                 log[name] = self.decode_first_stage(samples_cfg)
         return log
 
+    @torch.no_grad()
+    def interpolate(self, batch: dict, alphas, x_T: Optional[torch.Tensor] = None, ref2_key: str = 'ref_img2',
+                    unconditional_guidance_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+        """Makeup interpolation between two references (README.md:23-25 shows the figure; the reference has no code, so the
+        definition is this build's: the ControlNet hint embeddings E(src||ref1), E(src||ref2) are blended per sample with
+        weight alpha before the 50-step loop).  batch holds src_img, ref_img, `ref2_key`, txt_emb for
+        N pairs; every pair is sampled at every alpha -> latents [N*len(alphas), 4, h, w] ordered pair-major."""
+        src = self.get_origin_img_input(batch, self.src_img_key)
+        r1 = self.get_origin_img_input(batch, self.ref_img_key)
+        r2 = self.get_origin_img_input(batch, ref2_key)
+        ctx = self.get_cond_txt_coding(batch)
+        A = torch.as_tensor(list(alphas), dtype=torch.float32)
+        n, k = src.shape[0], A.numel()
+        rep = lambda t: t.repeat_interleave(k, 0)
+        h1, h2 = rep(torch.cat((src, r1), 1)), rep(torch.cat((src, r2), 1))
+        ctxr, al = rep(ctx), A.repeat(n).to(self.device)
+        eng = self._require_engine()
+        h, w = src.shape[2] // 8, src.shape[3] // 8
+        if x_T is None:
+            x_T = torch.randn(n, self.channels, h, w, device=self.device)
+        x_T = rep(x_T.to(self.device))           # the same start noise for every alpha of a pair
+        sch = self.schedule
+        sch.make_ddim(self.ddim_steps, ddim_eta=0.0)
+        if unconditional_guidance_scale != 1.0:
+            u = self.get_unconditional_conditioning(n * k)
+            eng.prepare(torch.cat([h1, h1]), torch.cat([u, ctxr]), hint2=torch.cat([h2, h2]), alpha=torch.cat([al, al]),
+                        control_scales=self.control_scales, only_mid_control=self.only_mid_control)
+        else:
+            eng.prepare(h1, ctxr, hint2=h2, alpha=al, control_scales=self.control_scales, only_mid_control=self.only_mid_control)
+        self._bound = None
+        lat = eng.sample(x_T, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
+                         cfg_scale=float(unconditional_guidance_scale), use_graph=True)
+        out = {'samples_latent': lat, 'alpha': al}
+        if self.has_first_stage:
+            out['samples'] = self.decode_first_stage(lat)
+        return out
+
     def test_step(self, batch: dict, batch_idx: int) -> Dict[str, torch.Tensor]:
         images = self.log_results(batch, batch_idx)
         for k in images:

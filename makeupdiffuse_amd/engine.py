@@ -236,7 +236,8 @@ class MkdEngine:
 
     # ---- conditioning / eval -----------------------------------------------------------------------
     def prepare(self, hint: Optional[torch.Tensor], context: torch.Tensor, latent_hw: Optional[Tuple[int, int]] = None,
-                control_scales: Optional[Sequence[float]] = None, only_mid_control: bool = False) -> None:
+                control_scales: Optional[Sequence[float]] = None, only_mid_control: bool = False,
+                hint2: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None) -> None:
         """hint [B,6,8h,8w] in [0,1] or None (c_concat is None); context [B,77,ctx_dim]."""
         B = context.shape[0]
         ctx = _f32c(context, self.device)
@@ -259,10 +260,23 @@ class MkdEngine:
             if len(control_scales) != self.cfg.n_control:
                 raise ValueError(f'control_scales must have {self.cfg.n_control} entries')
             scales = (C.c_float * len(control_scales))(*[float(s) for s in control_scales])
+        hint2_t = alpha_t = None
+        if hint2 is not None:
+            if hint_t is None or alpha is None:
+                raise ValueError('interpolation needs hint, hint2 and alpha')
+            hint2_t = _f32c(hint2, self.device)
+            alpha_t = _f32c(alpha, self.device).reshape(-1)
+            if tuple(hint2_t.shape) != tuple(hint_t.shape) or alpha_t.shape[0] != B:
+                raise ValueError('hint2 must match hint and alpha must have one entry per sample')
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mkd_prepare(self._ctx, B, h, w, C.c_void_p(_ptr(hint_t)), C.c_void_p(ctx.data_ptr()),
-                                            scales, int(bool(only_mid_control)), C.c_void_p(_stream())), 'mkd_prepare')
-        self._keep = [hint_t, ctx]
+            if hint2_t is None:
+                _lib.check(self.lib.mkd_prepare(self._ctx, B, h, w, C.c_void_p(_ptr(hint_t)), C.c_void_p(ctx.data_ptr()),
+                                                scales, int(bool(only_mid_control)), C.c_void_p(_stream())), 'mkd_prepare')
+            else:
+                _lib.check(self.lib.mkd_prepare_interp(self._ctx, B, h, w, C.c_void_p(hint_t.data_ptr()), C.c_void_p(hint2_t.data_ptr()),
+                                                       C.c_void_p(alpha_t.data_ptr()), C.c_void_p(ctx.data_ptr()), scales,
+                                                       int(bool(only_mid_control)), C.c_void_p(_stream())), 'mkd_prepare_interp')
+        self._keep = [hint_t, ctx, hint2_t, alpha_t]
         self.batch, self.latent_hw = B, (h, w)
 
     def eps(self, x: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -49,6 +49,7 @@ SIGNATURES = {
     'mkd_param_name': (C.c_char_p, [_P, _I]),
     'mkd_param_shape': (_I, [_P, _I, C.POINTER(_L)]),
     'mkd_prepare': (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_F), _I, _P]),
+    'mkd_prepare_interp': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_eps': (_I, [_P, _P, _P, _P, _P]),
     'mkd_ddim_step': (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _P, _L, _P]),
     'mkd_sample': (_I, [_P, _P, _I, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _P, _I, _P]),

@@ -327,10 +327,17 @@ def hint_block(sd: SD, p: str, hint: Tensor) -> Tensor:
 
 
 def control_model(sd: SD, cfg: NetConfig, x: Tensor, hint: Tensor, timesteps: Tensor, context: Tensor,
-                  prefix: str = CONTROL_PREFIX) -> List[Tensor]:
-    """cldm ControlNet.forward as called at reference makeup_diffuse.py:164-165 -> 13 residuals."""
+                  prefix: str = CONTROL_PREFIX, hint2: Optional[Tensor] = None, alpha: Optional[Tensor] = None) -> List[Tensor]:
+    """cldm ControlNet.forward as called at reference makeup_diffuse.py:164-165 -> 13 residuals.
+
+    hint2 / alpha: BUILD-DEFINED makeup interpolation (the reference has no code for it, only README.md:23-25):
+    the two hint embeddings E(src||ref1), E(src||ref2) are blended per sample, (1-alpha) E1 + alpha E2, before
+    they enter the ControlNet ('blend the two cached hint embeddings')."""
     emb = time_embed(sd, prefix, timesteps, cfg.model_channels)
     guided = hint_block(sd, prefix, hint)
+    if hint2 is not None:
+        a = alpha.view(-1, 1, 1, 1).to(guided.dtype)
+        guided = (1.0 - a) * guided + a * hint_block(sd, prefix, hint2)
     outs = []
     h = x
     for i, b in enumerate(encoder_spec(cfg)):

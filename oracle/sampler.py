@@ -62,7 +62,9 @@ def apply_model(sd, cfg: nets.NetConfig, x_noisy: Tensor, t: Tensor, cond: dict,
     if cond['c_concat'] is None:
         return nets.diffusion_model(sd, cfg, x_noisy, t, cond_txt, control=None,
                                     only_mid_control=only_mid_control)
-    control = nets.control_model(sd, cfg, x_noisy, torch.cat(cond['c_concat'], 1), t, cond_txt)
+    hint2 = torch.cat(cond['c_concat2'], 1) if cond.get('c_concat2') is not None else None
+    control = nets.control_model(sd, cfg, x_noisy, torch.cat(cond['c_concat'], 1), t, cond_txt, hint2=hint2,
+                                 alpha=cond.get('interp_alpha'))
     scales = control_scales if control_scales is not None else [1.0] * len(control)
     control = [c * s for c, s in zip(control, scales)]
     return nets.diffusion_model(sd, cfg, x_noisy, t, cond_txt, control=control,

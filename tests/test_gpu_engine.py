@@ -103,6 +103,37 @@ def test_small_sample_loop(small):
     assert torch.allclose(outg, out, rtol=1e-5, atol=1e-6), (outg - out).abs().max()
 
 
+def test_makeup_interpolation_vs_oracle(small):
+    """BASELINE config 5 (build-defined: blend of the two cached hint embeddings): eps and a 5-step latent vs
+    the oracle's restatement of the same definition; alpha = 0 / 1 must reduce to the single-reference path."""
+    eng, sd, ocfg, g = small
+    gen = torch.Generator().manual_seed(17)
+    B = 3
+    x = torch.randn(B, 4, 8, 8, generator=gen)
+    src = torch.rand(B, 3, 64, 64, generator=gen); r1 = torch.rand(B, 3, 64, 64, generator=gen); r2 = torch.rand(B, 3, 64, 64, generator=gen)
+    ctx = torch.randn(B, 77, ocfg.context_dim, generator=gen)
+    h1, h2 = torch.cat([src, r1], 1), torch.cat([src, r2], 1)
+    alpha = torch.tensor([0.0, 0.3, 1.0])
+    t = torch.tensor([601, 601, 601])
+    cond = {'c_crossattn': [ctx], 'c_concat': [h1], 'c_concat2': [h2], 'interp_alpha': alpha}
+    ref = sampler.apply_model(sd, ocfg, x, t, cond)
+    eng.prepare(h1, ctx, hint2=h2, alpha=alpha)
+    out = eng.eps(x, t)
+    check_eps(out, ref, what='interp eps')
+    eng.prepare(h1, ctx)
+    only1 = eng.eps(x, t)
+    eng.prepare(h2, ctx)
+    only2 = eng.eps(x, t)
+    check_eps(out[0:1], only1[0:1], rel=1e-6, cos=0.999999, what='alpha=0 == reference 1')
+    check_eps(out[2:3], only2[2:3], rel=1e-6, cos=0.999999, what='alpha=1 == reference 2')
+    assert (out[1] - only1[1]).abs().max() > 1e-3 and (out[1] - only2[1]).abs().max() > 1e-3
+    sch = sampler.Schedule().make_ddim(5)
+    ref5 = sampler.sample(sampler.make_eps_fn(sd, ocfg), sampler.Schedule(), x, cond, 5)
+    eng.prepare(h1, ctx, hint2=h2, alpha=alpha)
+    out5 = eng.sample(x, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas, use_graph=True)
+    check_eps(out5, ref5, rel=6e-2, cos=0.99, what='interp 5-step latent')
+
+
 VSMALL = dict(z_channels=4, embed_dim=4, ch=32, ch_mult=(1, 2), num_res_blocks=1, out_ch=3)
 
 
