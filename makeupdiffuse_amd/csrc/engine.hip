@@ -1386,6 +1386,7 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
     mkd_ctx* c = new mkd_ctx();
     c->cfg = *cfg;
     if (const char* fl = getenv("MKD_FUSE_LN")) c->fuse_ln = fl[0] == '1';
+    if (const char* sc = getenv("MKD_SPLITK_CAP")) gemm_set_splitk_cap(atoi(sc));
     c->build_param_spec();
     *out = c;
     return 0;

@@ -328,6 +328,8 @@ static const TunedEntry* tuned_lookup(int M, int N, int K, int conv, int stride,
 }
 
 static int g_force_cfg = -1;     // tuner / tests only
+static int g_splitk_cap = 0;      // experiment knob (MKD_SPLITK_CAP): 0 = no cap
+void gemm_set_splitk_cap(int cap) { g_splitk_cap = cap; }
 void gemm_force_tile_cfg(int cfg) { g_force_cfg = (cfg >= 0 && cfg < N_TILE_CFG) ? cfg : -1; }
 
 // Tile + split-K choice.  Large problems take the big tiles (more FLOP per byte staged through L2 -> LDS,
@@ -342,7 +344,8 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
         GemmPlan g;
         g.cfg = te->cfg;
         const int units = is_patch_cfg(te->cfg) ? (K / 9) / BK : nk;     // patch conv splits over channel chunks
-        const int s0 = te->splitk < units ? te->splitk : units;
+        int s0 = te->splitk < units ? te->splitk : units;
+        if (g_splitk_cap > 0 && s0 > g_splitk_cap) s0 = g_splitk_cap;
         g.per = (units + s0 - 1) / s0;
         g.splitk = (units + g.per - 1) / g.per;
         return g;

@@ -83,6 +83,7 @@ int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
 int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
+void gemm_set_splitk_cap(int cap);
 int  gemm_num_tile_cfgs();
 const char* gemm_tile_cfg_name(int cfg);
 int  launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream);
