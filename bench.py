@@ -154,6 +154,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU path for the product)')
+    if os.environ.get('MKD_BENCH_SINGLE_DEVICE') == '1':      # rehearsal of the N>1 path on a 1-GPU box (with MKD_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f'cuda:{local}')
 

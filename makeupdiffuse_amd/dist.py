@@ -30,7 +30,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('MKD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -53,8 +53,15 @@ def gather_shards(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor
     pad = local
     if local.shape[0] < cap:
         pad = torch.cat([local, local.new_zeros((cap - local.shape[0],) + tuple(local.shape[1:]))])
-    out = local.new_empty((world * cap,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if pad.is_cuda and dist.get_backend(group) == 'gloo':
+        # rehearsal mode (several ranks on one card): gloo gathers host tensors
+        host = pad.cpu().contiguous()
+        out_h = host.new_empty((world * cap,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(pad.device)
+    else:
+        out = local.new_empty((world * cap,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     parts = []
     for r in range(world):
         l, h = shard_range(n_total, r, world)
@@ -70,6 +77,8 @@ def barrier():
 def max_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return value
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
