@@ -127,13 +127,16 @@ struct mkd_ctx {
     int n_ctrl() const { return (int)encoder_spec().size() + 1; }
     Arena persist, temp_arena[2];
     int cur_sid = 0;
-    Arena& TA() { return temp_arena[cur_sid]; }
+    Arena& TA() { return temp_arena[cur_sid ? 1 : 0]; }      // sid 0 main, 1 side (ControlNet), 2 decoder helpers: side unless capturing
     char* persist_base = nullptr; char* temp_base[2] = {nullptr, nullptr};
     size_t persist_cap = 0, temp_cap[2] = {0, 0};
     float* splitk_ws[2] = {nullptr, nullptr}; size_t splitk_ws_bytes[2] = {0, 0}, splitk_need = 0;
     float* gn_ws[2] = {nullptr, nullptr}; size_t gn_ws_bytes[2] = {0, 0}, gn_need = 0;
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
+    bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
+    bool capturing = false;
+    std::vector<hipEvent_t> aux_ev; int aux_used = 0;        // cross-stream edges inside the decoder (re-used across plan rebuilds)
     std::vector<Op> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
     bool dry = false; bool counting_eps = false;
@@ -520,7 +523,7 @@ struct mkd_ctx {
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
         const int sid = cur_sid;
-        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[sid]; return launch_gemm(b, st); },
+        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[sid ? 1 : 0]; return launch_gemm(b, st); },
              s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
              (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0),
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
@@ -554,7 +557,7 @@ struct mkd_ctx {
         Tensor t = in;
         const int sid = cur_sid;
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out, sid](hipStream_t st) {
-            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[sid], st);
+            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[sid ? 1 : 0], st);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
@@ -576,9 +579,21 @@ struct mkd_ctx {
     }
 
     // ResBlock (App. A.2).  x may be a concat buffer (ld == C).  Writes [rows, cout] at (out, ldo).
-    void resblock(const std::string& p, const Tensor& x, int cout, const float* embproj, int ld_emb, bf16_t* out, int ldo) {
+    // side_skip: run the 1x1 skip_connection GEMM on the side stream, concurrently with GN -> conv -> GN (decoder only:
+    // the side stream is idle there).
+    void resblock(const std::string& p, const Tensor& x, int cout, const float* embproj, int ld_emb, bf16_t* out, int ldo,
+                  bool side_skip = false) {
         const size_t mk = TA().mark();
         const int rows = x.rows(), hw = x.H * x.W;
+        Tensor t4;
+        if (x.C != cout && side_skip) {
+            t4 = talloc(TA(), x.B, x.H, x.W, cout);
+            op_edge(0, 1);                               // side waits for the block input (written on main)
+            cur_sid = dec_overlap ? 2 : 0;
+            Epi es; es.bias = wf(p + ".skip_connection.bias");
+            op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
+            cur_sid = 0;
+        }
         Tensor t1 = talloc(TA(), x.B, x.H, x.W, x.C);
         op_gn(x, wf(p + ".in_layers.0.weight"), wf(p + ".in_layers.0.bias"), 1e-5f, 1, t1.p, t1.ld);
         Tensor t2 = talloc(TA(), x.B, x.H, x.W, cout);
@@ -587,8 +602,11 @@ struct mkd_ctx {
         Tensor t3 = talloc(TA(), x.B, x.H, x.W, cout);
         op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
         Epi e2; e2.bias = wf(p + ".out_layers.3.bias");
-        if (x.C != cout) {
-            Tensor t4 = talloc(TA(), x.B, x.H, x.W, cout);
+        if (x.C != cout && side_skip) {
+            op_edge(1, 0);                               // main waits for the skip GEMM
+            e2.R = t4.p; e2.ldr = t4.ld;
+        } else if (x.C != cout) {
+            t4 = talloc(TA(), x.B, x.H, x.W, cout);
             Epi es; es.bias = wf(p + ".skip_connection.bias");
             op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
             e2.R = t4.p; e2.ldr = t4.ld;
@@ -832,15 +850,26 @@ struct mkd_ctx {
 
         auto dec = decoder_spec();
         const std::string P = net_prefix(0), PC = net_prefix(1);
-        // first concat buffer: [mid (+control mid) | hs[last] (+control)]
-        Tensor cat;
+        // Concat buffers of all decoder blocks: [h (from the previous block / mid) | skip (+ control residual)].
+        // The "combine" GEMMs that fill the skip halves (zero-conv * scale + UNet skip) only depend on the two encoders,
+        // so they run on the side stream AHEAD of the decoder, interleaved with the blocks' 1x1 skip GEMMs; the main
+        // stream waits per block on an event.
         int n_skip = (int)hs.size();
-        for (size_t i = 0; i < dec.size(); ++i) {
+        std::vector<Tensor> cats(dec.size());
+        {
+            int Hc = hs[n_skip - 1].H, Wc = hs[n_skip - 1].W;
+            for (size_t i = 0; i < dec.size(); ++i) {
+                cats[i] = talloc(persist, B, Hc, Wc, dec[i].cin);
+                if (dec[i].up) { Hc *= 2; Wc *= 2; }
+            }
+        }
+        auto combine = [&](size_t i) {          // emits on the CURRENT sid
             const BlockSpec& b = dec[i];
-            const Tensor& skip = hs[n_skip - 1 - (int)i];
+            const int si = n_skip - 1 - (int)i;
+            const Tensor& skip = hs[si];
             const int ch_h = b.cin - skip.C;
+            Tensor& cat = cats[i];
             if (i == 0) {
-                cat = talloc(persist, skip.B, skip.H, skip.W, b.cin);
                 if (has_control) {
                     Epi e; e.bias = wf(PC + "middle_block_out.0.bias"); e.scale = scales[n_ctrl() - 1]; e.R = u_mid.p; e.ldr = u_mid.ld;
                     op_linear(cn_mid.p, cn_mid.ld, cn_mid.rows(), cn_mid.C, wb(PC + "middle_block_out.0.weight"), cn_mid.C, e, cat.p, cat.ld);
@@ -848,8 +877,6 @@ struct mkd_ctx {
                     op_copy(u_mid.p, u_mid.ld, cat.p, cat.ld, u_mid.rows(), u_mid.C);
                 }
             }
-            // skip half of this block's concat input
-            const int si = n_skip - 1 - (int)i;
             if (has_control && !only_mid) {
                 const Tensor& cf = cn_feats[si];
                 Epi e; e.bias = wf(PC + "zero_convs." + std::to_string(si) + ".0.bias"); e.scale = scales[si]; e.R = skip.p; e.ldr = skip.ld;
@@ -857,12 +884,21 @@ struct mkd_ctx {
             } else {
                 op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
             }
+        };
+        op_edge(0, 1);                          // side: both encoders are complete (main already joined the ControlNet)
+        cur_sid = dec_overlap ? 2 : 0; combine(0); cur_sid = 0;
+        Tensor cat;
+        for (size_t i = 0; i < dec.size(); ++i) {
+            const BlockSpec& b = dec[i];
+            cat = cats[i];
+            op_edge(1, 0);                      // main: this block's concat input is complete
+            if (i + 1 < dec.size()) { cur_sid = dec_overlap ? 2 : 0; combine(i + 1); cur_sid = 0; }      // next block's combine runs under this block
             // where does this block's output go?  next concat buffer's h half (or the final tensor)
             const std::string p = P + "output_blocks." + std::to_string(i);
             Tensor nxt_cat; bf16_t* dst; int dst_ld;
             const int outH = b.up ? cat.H * 2 : cat.H, outW = b.up ? cat.W * 2 : cat.W;
             if (i + 1 < dec.size()) {
-                nxt_cat = talloc(persist, cat.B, outH, outW, dec[i + 1].cin);
+                nxt_cat = cats[i + 1];
                 dst = nxt_cat.p; dst_ld = nxt_cat.ld;
             } else {
                 nxt_cat = talloc(persist, cat.B, outH, outW, b.cout);
@@ -878,7 +914,7 @@ struct mkd_ctx {
                 Tensor o; bf16_t* op_; int ol;
                 if (stage == stages) { op_ = dst; ol = dst_ld; o.p = dst; }
                 else { o = talloc(TA(), cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
-                resblock(p + ".0", cur_in, b.cout, ep0, emb_total[0], op_, ol);
+                resblock(p + ".0", cur_in, b.cout, ep0, emb_total[0], op_, ol, /*side_skip=*/true);
                 cur_in.p = op_; cur_in.C = b.cout; cur_in.ld = ol;
             }
             if (b.attn) {
@@ -961,7 +997,7 @@ struct mkd_ctx {
             dry = false;
             persist.base = persist_base; persist.reset();
             for (int i = 0; i < 2; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
-            cur_sid = 0;
+            cur_sid = 0; aux_used = 0;
             build_prepare_plan(); build_eps_plan();
             ++plan_generation; drop_graph();
             // sampler buffers
@@ -984,10 +1020,33 @@ struct mkd_ctx {
         io_x = x; io_t = t; io_out = out;
         run_main = stream; run_serial = !dual_stream;
         for (auto& op : plan_eps) {
-            int rc = op.fn((op.sid == 1 && !run_serial) ? side_stream : stream);
+            const bool on_side = !run_serial && (op.sid == 1 || (op.sid == 2 && !capturing));
+            int rc = op.fn(on_side ? side_stream : stream);
             if (rc) return rc;
         }
         return 0;
+    }
+
+    // ---- fine-grained cross-stream edges (decoder): event e recorded on stream `from`, awaited by stream `to` ----
+    int ev_new() {
+        if (dry) return -1;
+        if (aux_used == (int)aux_ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+            aux_ev.push_back(e);
+        }
+        return aux_used++;
+    }
+    void op_edge(int from_sid, int to_sid) {          // `to` waits for everything enqueued so far on `from`
+        if (!dec_overlap) return;
+        const int e = ev_new();
+        mkd_ctx* self = this;
+        push(*cur_plan, [self, e, from_sid, to_sid](hipStream_t) {
+            if (self->run_serial || self->capturing || e < 0) return 0;      // graph nodes pay for every cross-stream edge: keep the decoder linear there
+            MKD_HIP_CHECK(hipEventRecord(self->aux_ev[e], from_sid ? self->side_stream : self->run_main));
+            MKD_HIP_CHECK(hipStreamWaitEvent(to_sid ? self->side_stream : self->run_main, self->aux_ev[e], 0));
+            return 0;
+        }, 0, 0.0, K_MISC, from_sid ? "edge side->main" : "edge main->side");
     }
 
     // side stream starts after everything already enqueued on the caller's stream (x, t, previous eval)
@@ -1094,7 +1153,9 @@ struct mkd_ctx {
                 drop_graph();
                 hipGraph_t g = nullptr;
                 MKD_HIP_CHECK(hipStreamBeginCapture(loop_stream, hipStreamCaptureModeRelaxed));
+                capturing = true;
                 int rc = enqueue_state_step(batch, cfg_on, cfg_scale, loop_stream);
+                capturing = false;
                 hipError_t e = hipStreamEndCapture(loop_stream, &g);
                 if (rc) { if (g) hipGraphDestroy(g); return rc; }
                 if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1348,6 +1409,7 @@ struct mkd_ctx {
         if (varena_base) hipFree(varena_base);
         for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
+        for (hipEvent_t e : aux_ev) hipEventDestroy(e);
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
         if (h_state) hipHostFree(h_state);
         if (s_state) hipFree(s_state);
