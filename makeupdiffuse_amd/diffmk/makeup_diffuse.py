@@ -9,6 +9,7 @@ calling them raises NotImplementedError rather than returning something differen
 The arithmetic runs in libmkd (HIP); there is no CPU implementation behind these classes."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -241,7 +242,7 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
     """Reference Test* harness classes (diffmk/diffusion_makeup.py:308-411, diffmk/makeup_diffuse.py:413-464):
     adds the sampling settings and ``log_results``' two DDIM passes."""
 
-    def __init__(self, saved_dir: str = './results', model_name: str = 'makeupdiffuse', img_name_key: str = 'name',
+    def __init__(self, saved_dir: str = './results', model_name: str = 'makeupdiffuse', img_name_key: str = 'img_name',
                  unconditional_guidance_scale: float = 9, ddim_steps: int = 50, ddim_eta: float = 0.0, sample: bool = True,
                  *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -250,7 +251,19 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
         self.saved_dir, self.model_name, self.img_name_key = saved_dir, model_name, img_name_key
         self.clamp = True
         self.rescale = True
+        self.save_images = True                    # save_local after every test_step, as the reference does
         self.test_pairs: list = []
+        self.test_pairs_file = 'test_0412_pairs.txt'
+
+    def on_test_epoch_start(self) -> None:
+        self.eval()
+        self.test_pairs = []
+
+    def on_test_batch_end(self, outputs=None, batch=None, batch_idx: int = 0, dataloader_idx: int = 0) -> None:
+        """'num-num nonmakeup makeup' bookkeeping file (diffusion_makeup.py:327-331), rewritten after every batch."""
+        with open(self.test_pairs_file, 'w') as f:
+            for tp in self.test_pairs:
+                f.write('%s %s %s\n' % (tp[0], tp[1], tp[2]))
 
     @torch.no_grad()
     def log_results(self, batch: dict, batch_idx: int, x_T: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -264,6 +277,11 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
         src, ref = torch.chunk(c_cat, 2, dim=1)
         log['control_src'] = src * 2.0 - 1.0
         log['control_ref'] = ref * 2.0 - 1.0
+        names = batch.get(self.img_name_key)
+        if names is not None:                      # :379-384
+            for i, nm in enumerate(names):
+                self.test_pairs.append(['%04d-%d' % (batch_idx, i + 1), 'non-makeup/%s.png' % nm.split('&')[0],
+                                        'makeup/%s.png' % nm.split('&')[1]])
         b = c_cat.shape[0]
         extra = {} if x_T is None else {'x_T': x_T}
         cond = {'c_concat': [c_cat], 'c_crossattn': [c_txt]}
@@ -328,4 +346,19 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
                 images[k] = images[k].detach().cpu()
                 if self.clamp and not k.endswith('_latent'):
                     images[k] = torch.clamp(images[k], -1.0, 1.0)
+        if self.save_images:
+            self.save_local(images, batch_idx)
         return images
+
+    def save_local(self, images: Dict[str, torch.Tensor], batch_idx: int) -> List[str]:
+        """One PNG grid per image-valued log entry under saved_dir/model_name (diffusion_makeup.py:344-358; the
+        reference's nrow = number of log entries is kept).  Latents (4 channels) are not images and are skipped."""
+        from ..imageio import save_grid_png
+        root = os.path.join(self.saved_dir, self.model_name)
+        nrow = len(images)
+        written = []
+        for k, v in images.items():
+            if not isinstance(v, torch.Tensor) or v.dim() != 4 or v.shape[1] not in (1, 3):
+                continue
+            written.append(save_grid_png(v, os.path.join(root, '{}_{:04}.png'.format(k, batch_idx)), nrow, self.rescale))
+        return written

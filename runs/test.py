@@ -28,7 +28,7 @@ def synthetic_batch(lo, hi, res, ctx_dim):
         g = torch.Generator().manual_seed(91011 + i)
         txt.append(torch.randn(1, 77, ctx_dim, generator=g))
     return {'src_img': torch.cat(src), 'ref_img': torch.cat(ref), 'txt_emb': torch.cat(txt),
-            'name': [f'{i:04d}&{i:04d}' for i in range(lo, hi)]}
+            'txt': ['makeup transfer'] * (hi - lo), 'img_name': [f'{i:04d}&{i:04d}' for i in range(lo, hi)]}
 
 
 def main():
@@ -41,6 +41,9 @@ def main():
     ap.add_argument('--ddim-steps', type=int, default=None)
     ap.add_argument('--only-mid-control', action='store_true')
     ap.add_argument('--out', default='./results')
+    ap.add_argument('--data-root', default=None, help='folder with images/ and a pairs file (reference TestFixed_Dataset layout)')
+    ap.add_argument('--pairs-file', default='test_0412.txt')
+    ap.add_argument('--txt-emb', default=None, help='.pt/.safetensors with a [1,77,768] tensor: the CLIP embedding of the prompt (offline stand-in)')
     args = ap.parse_args()
 
     rank, world, local = mdist.init_from_env()
@@ -57,11 +60,32 @@ def main():
     model.uncond_embedding = torch.zeros(1, 77, model.net_config.context_dim)   # stands for CLIP("") offline
     model.eval()
 
+    model.saved_dir = args.out
+    model.test_pairs_file = os.path.join(args.out, f'test_pairs_rank{rank}.txt')
+    dataset = None
+    if args.data_root:
+        from makeupdiffuse_amd.imageio import PairFolderDataset, collate
+        dataset = PairFolderDataset(args.data_root, args.pairs_file, (args.res, args.res))
+        args.pairs = len(dataset)
+    txt_emb = None
+    if args.txt_emb:
+        t = load_state_dict(args.txt_emb)
+        txt_emb = (next(iter(t.values())) if isinstance(t, dict) else t).float().reshape(1, 77, -1)
     lo, hi = mdist.shard_range(args.pairs, rank, world)
     os.makedirs(args.out, exist_ok=True)
+    model.on_test_epoch_start()
     for b0 in range(lo, hi, args.batch_size):
-        batch = synthetic_batch(b0, min(hi, b0 + args.batch_size), args.res, model.net_config.context_dim)
+        b1 = min(hi, b0 + args.batch_size)
+        if dataset is not None:
+            batch = collate([dataset[i] for i in range(b0, b1)])
+            if model.cond_stage_model is None:
+                g = torch.Generator().manual_seed(91011)
+                e = txt_emb if txt_emb is not None else torch.randn(1, 77, model.net_config.context_dim, generator=g)
+                batch['txt_emb'] = e.expand(b1 - b0, -1, -1).contiguous()
+        else:
+            batch = synthetic_batch(b0, b1, args.res, model.net_config.context_dim)
         out = model.test_step(batch, b0)
+        model.on_test_batch_end(out, batch, b0)
         torch.save({k: v for k, v in out.items() if isinstance(v, torch.Tensor)},
                    os.path.join(args.out, f'latents_{b0:04d}.pt'))
         print(f'[rank {rank}] pairs {b0}..{min(hi, b0 + args.batch_size) - 1}: ' +
