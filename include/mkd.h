@@ -133,6 +133,26 @@ int mkd_vae_finalize(mkd_ctx* ctx);
 int mkd_decode(mkd_ctx* ctx, const float* z, int batch, int h, int w, float scale_factor, float* images, void* stream);
 double mkd_decode_flops(const mkd_ctx* ctx);
 
+/* ---- CLIP text encoder -------------------------------------------------- */
+/* yaml cond_stage_config FrozenCLIPEmbedder (diffmodels/base_diffusion_makeup.yaml:109-110), i.e. UPSTREAM transformers
+ * CLIPTextModel: token + position embeddings, `layers` pre-LN blocks (causal self-attention, quick-GELU MLP), final LN. */
+typedef struct mkd_clip_config {
+    int32_t vocab_size;      /* 49408 */
+    int32_t max_positions;   /* 77 */
+    int32_t width;           /* 768 */
+    int32_t layers;          /* 12 */
+    int32_t heads;           /* 12 */
+    int32_t intermediate;    /* 3072 */
+    float   ln_eps;          /* 1e-5 */
+} mkd_clip_config;
+/* Adds the "cond_stage_model.transformer.text_model.*" entries to the expected state_dict.  Optional. */
+int mkd_clip_configure(mkd_ctx* ctx, const mkd_clip_config* cfg);
+int mkd_clip_finalize(mkd_ctx* ctx);
+/* Replaces get_learned_conditioning / FrozenCLIPEmbedder.encode after tokenisation (diffmk/makeup_teacher.py:33-42,
+ * diffmk/diffusion_makeup.py:400): tokens [B, n_tokens] int32 (device; padded ids included, CLIP applies only the causal
+ * mask) -> last_hidden_state [B, n_tokens, width] fp32 (device). */
+int mkd_clip_encode(mkd_ctx* ctx, const int32_t* tokens, int batch, int n_tokens, float* out, void* stream);
+
 /* ---- introspection for bench.py ----------------------------------------------------------- */
 /* Executed matmul/conv FLOPs (2 per MAC) of one mkd_eps at the prepared shape. */
 double  mkd_eps_flops(const mkd_ctx* ctx);
@@ -184,6 +204,10 @@ int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, floa
 int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
                   uint16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
                   void* stream);
+/* same with the causal mask of the CLIP text encoder: query i attends keys 0..i (Tq == Tk). */
+int mkd_attention_causal(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
+                         uint16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
+                         void* stream);
 /* y[m, j] = x[m, j] * gelu_erf(x[m, inner + j]). */
 int mkd_geglu(const uint16_t* x, uint16_t* y, int rows, int inner, void* stream);
 /* direct 3x3 conv, pad 1, fp32 accumulate.  in_nchw_f32: x is fp32 NCHW else bf16 NHWC;

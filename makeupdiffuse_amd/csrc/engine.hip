@@ -147,6 +147,11 @@ struct mkd_ctx {
     const float* in_hint2 = nullptr; const float* in_alpha = nullptr; bool has_interp = false;   // makeup interpolation (build-defined)
     // ---- first-stage decoder (AutoencoderKL.decode) ----
     bool vae_configured = false, vae_finalized = false;
+    bool clip_configured = false, clip_finalized = false; mkd_clip_config ccfg{};
+    Arena carena; char* carena_base = nullptr; size_t carena_cap = 0;
+    std::vector<Op> plan_clip; int clip_B = 0, clip_T = 0;
+    const int32_t* io_tokens = nullptr; float* io_ctx_out = nullptr;
+    std::map<std::string, bf16_t*> clip_qkv_w; std::map<std::string, float*> clip_qkv_b;
     mkd_vae_config vcfg;
     std::map<std::string, bf16_t*> vae_fused;           // mid attention [Wq;Wk]
     std::map<std::string, float*> vae_fused_b;
@@ -364,7 +369,7 @@ struct mkd_ctx {
         if (rc) return rc;
         if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("load_weight sync: ") + hipGetErrorString(e));
         p.loaded = true;
-        if (p.which == 2) vae_finalized = false; else finalized = false;
+        if (p.which == 2) vae_finalized = false; else if (p.which == 3) clip_finalized = false; else finalized = false;
         return 0;
     }
 
@@ -1399,14 +1404,156 @@ struct mkd_ctx {
         return 0;
     }
 
+
+    // ---- CLIP text encoder ---------------------------------------------------------------
+    // cond_stage_config FrozenCLIPEmbedder (reference diffmodels/base_diffusion_makeup.yaml:109-110; called through
+    // get_learned_conditioning at diffmk/makeup_teacher.py:33-42 and get_unconditional_conditioning at
+    // diffmk/diffusion_makeup.py:400): UPSTREAM = transformers CLIPTextModel(...).last_hidden_state over 77 padded tokens.
+    static std::string clip_prefix() { return "cond_stage_model.transformer.text_model."; }
+
+    int clip_configure(const mkd_clip_config* c) {
+        if (clip_configured) return mkd_fail(MKD_ERR_STATE, "mkd_clip_configure: already configured");
+        if (c->vocab_size <= 0 || c->max_positions <= 0 || c->width <= 0 || c->layers <= 0 || c->heads <= 0 || c->intermediate <= 0 ||
+            c->width % c->heads || c->width % 8 || c->intermediate % 8)
+            return mkd_fail(MKD_ERR_UNSUPPORTED, "mkd_clip_configure: unsupported text-encoder configuration");
+        const int dh = c->width / c->heads;
+        if (!(dh == 8 || dh == 16 || dh == 32 || dh == 40 || dh == 64 || dh == 80 || dh == 160))
+            return mkd_fail(MKD_ERR_UNSUPPORTED, "mkd_clip_configure: head dim " + std::to_string(dh) + " has no attention kernel");
+        ccfg = *c;
+        if (ccfg.ln_eps <= 0.f) ccfg.ln_eps = 1e-5f;
+        const std::string P = clip_prefix();
+        const int64_t W = c->width, I = c->intermediate;
+        add_param(P + "embeddings.token_embedding.weight", {c->vocab_size, W}, 3);
+        add_param(P + "embeddings.position_embedding.weight", {c->max_positions, W}, 3);
+        for (int l = 0; l < c->layers; ++l) {
+            const std::string L = P + "encoder.layers." + std::to_string(l);
+            for (const char* n : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+                add_param(L + ".self_attn." + n + ".weight", {W, W}, 3); add_param(L + ".self_attn." + n + ".bias", {W}, 3);
+            }
+            add_param(L + ".layer_norm1.weight", {W}, 3); add_param(L + ".layer_norm1.bias", {W}, 3);
+            add_param(L + ".mlp.fc1.weight", {I, W}, 3); add_param(L + ".mlp.fc1.bias", {I}, 3);
+            add_param(L + ".mlp.fc2.weight", {W, I}, 3); add_param(L + ".mlp.fc2.bias", {W}, 3);
+            add_param(L + ".layer_norm2.weight", {W}, 3); add_param(L + ".layer_norm2.bias", {W}, 3);
+        }
+        add_param(P + "final_layer_norm.weight", {W}, 3); add_param(P + "final_layer_norm.bias", {W}, 3);
+        clip_configured = true;
+        return 0;
+    }
+
+    int clip_finalize() {
+        if (!clip_configured) return mkd_fail(MKD_ERR_STATE, "text encoder not configured (mkd_clip_configure)");
+        for (auto& kv : params)
+            if (kv.second.which == 3 && !kv.second.loaded) return mkd_fail(MKD_ERR_MISSING, "weight not loaded: " + kv.first);
+        if (clip_finalized) return 0;
+        if (!zero_page) {
+            void* z = nullptr;
+            int rc = dev_alloc(&z, 4096); if (rc) return rc;
+            MKD_HIP_CHECK(hipMemset(z, 0, 4096));
+            zero_page = (bf16_t*)z;
+        }
+        const int W = ccfg.width;
+        for (int l = 0; l < ccfg.layers; ++l) {          // one [3W, W] projection per layer: rows q | k | v
+            const std::string A = clip_prefix() + "encoder.layers." + std::to_string(l) + ".self_attn";
+            if (clip_qkv_w.count(A)) {                   // re-finalize after a weight reload: refresh in place
+                bf16_t* d = clip_qkv_w[A]; float* b = clip_qkv_b[A]; int j = 0;
+                for (const char* n : {".q_proj", ".k_proj", ".v_proj"}) {
+                    MKD_HIP_CHECK(hipMemcpy(d + (size_t)j * W * W, params.at(A + n + ".weight").dev, (size_t)W * W * sizeof(bf16_t), hipMemcpyDeviceToDevice));
+                    MKD_HIP_CHECK(hipMemcpy(b + (size_t)j * W, params.at(A + n + ".bias").dev, W * sizeof(float), hipMemcpyDeviceToDevice));
+                    ++j;
+                }
+                continue;
+            }
+            bf16_t* w = nullptr;
+            int rc = concat_rows(&w, {A + ".q_proj.weight", A + ".k_proj.weight", A + ".v_proj.weight"}); if (rc) return rc;
+            void* b = nullptr;
+            rc = dev_alloc(&b, 3 * W * sizeof(float)); if (rc) return rc;
+            int j = 0;
+            for (const char* n : {".q_proj.bias", ".k_proj.bias", ".v_proj.bias"}) {
+                MKD_HIP_CHECK(hipMemcpy((float*)b + (size_t)j * W, params.at(A + n).dev, W * sizeof(float), hipMemcpyDeviceToDevice));
+                ++j;
+            }
+            clip_qkv_w[A] = w; clip_qkv_b[A] = (float*)b;
+        }
+        MKD_HIP_CHECK(hipDeviceSynchronize());
+        clip_finalized = true;
+        clip_B = 0;
+        return 0;
+    }
+
+    void build_clip_plan(int Bn, int T) {
+        cur_plan = &plan_clip; cur_sid = 0; counting_eps = false;
+        mkd_ctx* self = this;
+        const std::string P = clip_prefix();
+        const int W = ccfg.width, I = ccfg.intermediate, heads = ccfg.heads, dh = W / heads, rows = Bn * T;
+        auto buf = [&](int cols) { return (bf16_t*)carena.alloc((size_t)rows * cols * sizeof(bf16_t)); };
+        bf16_t* X[2] = {buf(W), buf(W)};
+        bf16_t* ln = buf(W); bf16_t* qkv = buf(3 * W); bf16_t* att = buf(W); bf16_t* hid = buf(I);
+        {
+            const bf16_t* te = wb(P + "embeddings.token_embedding.weight"); const bf16_t* pe = wb(P + "embeddings.position_embedding.weight");
+            bf16_t* dst = X[0]; const int V = ccfg.vocab_size;
+            push(*cur_plan, [self, te, pe, dst, Bn, T, W, V](hipStream_t st) {
+                return launch_clip_embed(self->io_tokens, te, pe, dst, Bn, T, W, V, st); }, 1, 0.0, K_MISC, "clip_embed");
+        }
+        int cur = 0;
+        const float eps = ccfg.ln_eps;
+        auto op_ln_eps = [&](const bf16_t* x, const std::string& n, bf16_t* y) {
+            const float* g = wf(n + ".weight"); const float* b = wf(n + ".bias");
+            push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, g, b, eps, y, rows, W, st); }, 1, 0.0, K_LAYERNORM,
+                 "rows=" + std::to_string(rows) + " d=" + std::to_string(W));
+        };
+        for (int l = 0; l < ccfg.layers; ++l) {
+            const std::string L = P + "encoder.layers." + std::to_string(l), A = L + ".self_attn";
+            op_ln_eps(X[cur], L + ".layer_norm1", ln);
+            { Epi e; e.bias = dry ? nullptr : clip_qkv_b.at(A); op_linear(ln, W, rows, W, dry ? nullptr : clip_qkv_w.at(A), 3 * W, e, qkv, 3 * W); }
+            {   // causal self-attention over the T padded tokens (CLIP applies no padding mask, only the causal one)
+                const float scale = 1.0f / sqrtf((float)dh);
+                const bf16_t* q = qkv; bf16_t* o = att;
+                push(*cur_plan, [=](hipStream_t st) { return launch_attention(q, 3 * W, q + W, 3 * W, q + 2 * W, 3 * W, o, W, Bn, T, T, heads, dh, scale, st, 1); },
+                     1, 4.0 * Bn * heads * (double)T * T * dh, K_ATTENTION, "clip causal B=" + std::to_string(Bn) + " T=" + std::to_string(T));
+            }
+            { Epi e; e.bias = wf(A + ".out_proj.bias"); e.R = X[cur]; e.ldr = W; op_linear(att, W, rows, W, wb(A + ".out_proj.weight"), W, e, X[cur ^ 1], W); }
+            cur ^= 1;
+            op_ln_eps(X[cur], L + ".layer_norm2", ln);
+            { Epi e; e.bias = wf(L + ".mlp.fc1.bias"); e.act = 3; op_linear(ln, W, rows, W, wb(L + ".mlp.fc1.weight"), I, e, hid, I); }
+            { Epi e; e.bias = wf(L + ".mlp.fc2.bias"); e.R = X[cur]; e.ldr = W; op_linear(hid, I, rows, I, wb(L + ".mlp.fc2.weight"), W, e, X[cur ^ 1], W); }
+            cur ^= 1;
+        }
+        op_ln_eps(X[cur], P + "final_layer_norm", ln);
+        {
+            const int64_t n = (int64_t)rows * W;
+            push(*cur_plan, [self, ln, n](hipStream_t st) { return launch_bf16_to_f32(ln, self->io_ctx_out, n, st); }, 1, 0.0, K_MISC, "clip_out");
+        }
+    }
+
+    int clip_encode(const int32_t* tokens, int Bn, int T, float* out, hipStream_t stream) {
+        if (!clip_finalized) { int rc = clip_finalize(); if (rc) return rc; }
+        if (!tokens || !out || Bn <= 0 || T <= 0) return mkd_fail(MKD_ERR_ARG, "mkd_clip_encode: bad arguments");
+        if (T > ccfg.max_positions) return mkd_fail(MKD_ERR_ARG, "mkd_clip_encode: more tokens than position embeddings");
+        if (Bn != clip_B || T != clip_T) {
+            const size_t keep_sk = splitk_need;
+            dry = true; carena.base = nullptr; carena.reset(); plan_clip.clear();
+            build_clip_plan(Bn, T);
+            int rc = ensure((void**)&carena_base, &carena_cap, carena.high + 256); if (rc) return rc;
+            rc = ensure((void**)&splitk_ws[0], &splitk_ws_bytes[0], std::max(splitk_need, keep_sk)); if (rc) return rc;
+            dry = false; carena.base = carena_base; carena.reset(); plan_clip.clear();
+            build_clip_plan(Bn, T);
+            clip_B = Bn; clip_T = T;
+            drop_graph();            // workspaces may have moved
+        }
+        io_tokens = tokens; io_ctx_out = out;
+        for (auto& op : plan_clip) { int rc = op.fn(stream); if (rc) return rc; }
+        return 0;
+    }
+
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)varena_cap + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
+        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
                (int64_t)(gn_ws_bytes[0] + gn_ws_bytes[1]);
     }
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
         if (varena_base) hipFree(varena_base);
+        if (carena_base) hipFree(carena_base);
         for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
         for (hipEvent_t e : aux_ev) hipEventDestroy(e);
@@ -1536,6 +1683,15 @@ int mkd_decode(mkd_ctx* ctx, const float* z, int batch, int h, int w, float scal
     return ctx->decode(z, batch, h, w, scale_factor, images, (hipStream_t)stream);
 }
 double mkd_decode_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_vae : 0.0; }
+int mkd_clip_configure(mkd_ctx* ctx, const mkd_clip_config* cfg) {
+    if (!ctx || !cfg) return mkd_fail(MKD_ERR_ARG, "mkd_clip_configure: null argument");
+    return ctx->clip_configure(cfg);
+}
+int mkd_clip_finalize(mkd_ctx* ctx) { return ctx ? ctx->clip_finalize() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
+int mkd_clip_encode(mkd_ctx* ctx, const int32_t* tokens, int batch, int n_tokens, float* out, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->clip_encode(tokens, batch, n_tokens, out, (hipStream_t)stream);
+}
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }
 int64_t mkd_device_bytes(const mkd_ctx* ctx) { return ctx ? ctx->device_bytes() : 0; }
@@ -1624,6 +1780,10 @@ int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, floa
 int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
                   int batch, int Tq, int Tk, int heads, int dh, float scale, void* stream) {
     return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, batch, Tq, Tk, heads, dh, scale, (hipStream_t)stream);
+}
+int mkd_attention_causal(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
+                         int batch, int Tq, int Tk, int heads, int dh, float scale, void* stream) {
+    return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, batch, Tq, Tk, heads, dh, scale, (hipStream_t)stream, 1);
 }
 int mkd_geglu(const uint16_t* x, uint16_t* y, int rows, int inner, void* stream) {
     return launch_geglu(x, y, rows, inner, (hipStream_t)stream);

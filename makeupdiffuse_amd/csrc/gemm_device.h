@@ -54,6 +54,10 @@ __device__ __forceinline__ f32x4 epilogue_value(const Epilogue& e, int m, int n,
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
     }
+    if (e.act == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = quick_gelu_f(v[j]);
+    }
     return v;
 }
 

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ K, int ldk,
                                                         const bf16_t* __restrict__ V, int ldv,
                                                         bf16_t* __restrict__ O, int ldo,
-                                                        int Tq, int Tk, int heads, float scale_log2e) {
+                                                        int Tq, int Tk, int heads, float scale_log2e, int causal) {
     using C = AttnCfg<DH>;
     __shared__ __attribute__((aligned(16))) char smem[C::KBYTES + C::VBYTES];
     char* ks = smem;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const bf16_t* kbase = K + (size_t)b * Tk * ldk + h * DH;
     const bf16_t* vbase = V + (size_t)b * Tk * ldv + h * DH;
     const int ntiles = (Tk + KT - 1) / KT;
+    const int key_lim = causal ? (qi < Tk ? qi + 1 : Tk) : Tk;      // causal (CLIP text): query i sees keys 0..i; key 0 is always visible
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             for (int r = 0; r < 4; ++r) {
                 const int key = key0 + 16 * mf + 4 * g + r;
                 float s = st[mf][r] * scale_log2e;
-                s = key < Tk ? s : -INFINITY;
+                s = key < key_lim ? s : -INFINITY;
                 st[mf][r] = s;
                 mx = fmaxf(mx, s);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);              // finite: every tile has >= 1 valid key
+        const float m_new = fmaxf(m_run, mx);              // finite: the first tile always holds a visible key
         const float alpha = exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
-                     hipStream_t stream) {
+                     hipStream_t stream, int causal) {
     if (Tq <= 0 || Tk <= 0 || batch <= 0 || heads <= 0) return mkd_fail(-1, "attention: empty problem");
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
     dim3 grid((Tq + 63) / 64, batch * heads);
@@ -189,7 +190,7 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
 #define MKD_ATTN_CASE(D)                                                                                   \
     case D:                                                                                                \
         hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo, \
-                           Tq, Tk, heads, sl);                                                             \
+                           Tq, Tk, heads, sl, causal);                                                           \
         break;
     switch (dh) {
         MKD_ATTN_CASE(8)

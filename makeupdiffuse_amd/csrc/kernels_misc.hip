@@ -282,6 +282,30 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restri
         y[i] = f32_to_bf16(x[i]);
 }
 
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = bf16_to_f32(x[i]);
+}
+
+// CLIP text embeddings: out[b, t, :] = token_embedding[tokens[b, t]] + position_embedding[t]   (8 channels per thread)
+__global__ void clip_embed_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ tok_emb,
+                                  const bf16_t* __restrict__ pos_emb, bf16_t* __restrict__ out, int rows, int T, int width, int vocab) {
+    const int vper = width >> 3;
+    const int64_t total = (int64_t)rows * vper;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / vper);
+        const int c = (int)(idx - (int64_t)r * vper) << 3;
+        int id = tokens[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);        // the host wrapper rejects out-of-range ids; never read OOB
+        const U16x8 a = *(const U16x8*)(tok_emb + (size_t)id * width + c);
+        const U16x8 b = *(const U16x8*)(pos_emb + (size_t)(r % T) * width + c);
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = f32_to_bf16(bf16_to_f32(a.v[j]) + bf16_to_f32(b.v[j]));
+        *(U16x8*)(out + (size_t)r * width + c) = o;
+    }
+}
+
 __global__ void copy_strided_kernel(const bf16_t* __restrict__ src, int ld_src, bf16_t* __restrict__ dst, int ld_dst,
                                     int rows, int cols) {
     const int vper = cols >> 3;
@@ -383,6 +407,21 @@ int launch_pack_conv_weight(const float* w, bf16_t* out, int Cout, int Cin, int 
 int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n);
     MKD_LAUNCH_CHECK("f32_to_bf16_kernel");
+    return 0;
+}
+
+int launch_bf16_to_f32(const bf16_t* x, float* y, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n);
+    MKD_LAUNCH_CHECK("bf16_to_f32_kernel");
+    return 0;
+}
+
+int launch_clip_embed(const int32_t* tokens, const bf16_t* tok_emb, const bf16_t* pos_emb, bf16_t* out, int batch, int T, int width,
+                      int vocab, hipStream_t stream) {
+    if (width % 8) return mkd_fail(-1, "clip_embed: width must be a multiple of 8");
+    hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for((int64_t)batch * T * (width / 8))), dim3(256), 0, stream, tokens, tok_emb, pos_emb,
+                       out, batch * T, T, width, vocab);
+    MKD_LAUNCH_CHECK("clip_embed_kernel");
     return 0;
 }
 

@@ -41,6 +41,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }      // CLIP: x * sigmoid(1.702 x)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 struct __attribute__((aligned(16))) U16x8 { uint16_t v[8]; };
@@ -101,7 +102,7 @@ int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, flo
                      int rows, int d, hipStream_t stream);
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
-                     hipStream_t stream);
+                     hipStream_t stream, int causal = 0);
 int launch_geglu(const bf16_t* x, bf16_t* y, int rows, int inner, hipStream_t stream);
 int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
@@ -122,4 +123,7 @@ int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, flo
 int launch_softmax_rows(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t stream);
 int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float inv_scale, float* out, int batch, int C, int hw,
                       hipStream_t stream);
+int launch_clip_embed(const int32_t* tokens, const bf16_t* tok_emb, const bf16_t* pos_emb, bf16_t* out, int batch, int T, int width,
+                      int vocab, hipStream_t stream);
+int launch_bf16_to_f32(const bf16_t* x, float* y, int64_t n, hipStream_t stream);
 int launch_blend(const bf16_t* a, const bf16_t* b, const float* alpha, bf16_t* y, int64_t per_sample, int batch, hipStream_t stream);

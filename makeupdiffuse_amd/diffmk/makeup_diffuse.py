@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from ..ddim import DDIMSampler
-from ..engine import MkdEngine, NetConfig, VaeConfig
+from ..engine import ClipConfig, MkdEngine, NetConfig, VaeConfig
 from ..lib import MkdError
 from ..schedule import DDIMSchedule
 
@@ -42,6 +42,9 @@ class BaseMakeUpDiffuse:
         self.vae_config = None
         if first_stage_config is not None:
             self.vae_config = VaeConfig.from_yaml_params(dict(first_stage_config.get('params', first_stage_config)))
+        self.clip_config = None
+        if cond_stage_config is not None:
+            self.clip_config = ClipConfig.from_yaml_params(cond_stage_config.get('params'))
         self.extra_params = dict(unused_training_params)      # w_idt_src, lambda_lip, teacher_type, ... (training only)
         self.parameterization = parameterization
         self.only_mid_control = bool(only_mid_control)
@@ -62,7 +65,7 @@ class BaseMakeUpDiffuse:
         self._pending_sd: Optional[Dict[str, torch.Tensor]] = None
         self._bound = None
         self._cfg_cache = None
-        self.cond_stage_model = None          # callable(list[str]) -> [B,77,768]; CLIP is a "next" row
+        self.cond_stage_model = None          # callable(list[str]) -> [B,77,768]; built on .cuda() when cond_stage_config is set
         self.training = False
 
     # ---- nn.Module-ish surface used by runs/test.py --------------------------------------------------------
@@ -83,6 +86,13 @@ class BaseMakeUpDiffuse:
                 self.engine = MkdEngine(self.net_config, device)
                 if self.vae_config is not None:
                     self.engine.configure_vae(self.vae_config)
+                if self.clip_config is not None:
+                    from ..clip import FrozenCLIPEmbedder, load_tokenizer
+                    self.engine.configure_clip(self.clip_config)
+                    params = dict((self.cond_stage_config or {}).get('params') or {})
+                    tok_dir = params.get('tokenizer_path') or params.get('version')
+                    tok = load_tokenizer(tok_dir) if tok_dir and os.path.isdir(str(tok_dir)) else None
+                    self.cond_stage_model = FrozenCLIPEmbedder(self.engine, tok, max_length=self.clip_config.max_positions)
                 if self._pending_sd is not None:
                     self.engine.load_state_dict(self._pending_sd, strict=True)
                     self._pending_sd = None
@@ -101,7 +111,8 @@ class BaseMakeUpDiffuse:
         else:
             self._pending_sd = {k: v for k, v in sd.items()
                                 if k.startswith(MkdEngine.UNET_PREFIX) or k.startswith(MkdEngine.CONTROL_PREFIX)
-                                or k.startswith('first_stage_model.post_quant_conv.') or k.startswith('first_stage_model.decoder.')}
+                                or k.startswith('first_stage_model.post_quant_conv.') or k.startswith('first_stage_model.decoder.')
+                                or (k.startswith(MkdEngine.CLIP_PREFIX) and not k.endswith('position_ids'))}
             unused = [k for k in sd if k not in self._pending_sd]
         return [], unused
 
@@ -119,14 +130,17 @@ class BaseMakeUpDiffuse:
 
     def get_learned_conditioning(self, txt: Sequence[str]) -> torch.Tensor:
         if self.cond_stage_model is None:
-            raise NotImplementedError('CLIP text encoder (cond_stage_config) is not built yet (SURVEY.md §8f rank 3): '
-                                      "put a precomputed [B,77,768] embedding under batch['txt_emb'] or set cond_stage_model")
+            raise NotImplementedError('no cond_stage_config in the yaml and no cond_stage_model set: '
+                                      "put a precomputed [B,77,768] embedding under batch['txt_emb']")
         return self.cond_stage_model(list(txt)).to(self.device).float()
 
     def get_cond_txt_coding(self, batch: dict, bs: Optional[int] = None) -> torch.Tensor:
         if 'txt_emb' in batch:
             c = batch['txt_emb']
             return (c if bs is None else c[:bs]).to(self.device).float()
+        if 'txt_tokens' in batch and self.cond_stage_model is not None:      # ids from an external tokenizer
+            tk = batch['txt_tokens']
+            return self.cond_stage_model.encode_tokens(tk if bs is None else tk[:bs]).float()
         txt = batch[self.cond_stage_key]
         return self.get_learned_conditioning(txt if bs is None else txt[:bs])
 

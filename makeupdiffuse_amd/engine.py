@@ -97,6 +97,33 @@ class VaeConfig:
         return c
 
 
+@dataclass
+class ClipConfig:
+    """cond_stage_config FrozenCLIPEmbedder (diffmodels/base_diffusion_makeup.yaml:109-110): UPSTREAM default
+    openai/clip-vit-large-patch14 text tower (vocab 49408, 77 positions, width 768, 12 layers x 12 heads, MLP 3072, quick-GELU)."""
+    vocab_size: int = 49408
+    max_positions: int = 77
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 3072
+    ln_eps: float = 1e-5
+
+    @classmethod
+    def from_yaml_params(cls, cond_stage_params: Optional[dict]) -> 'ClipConfig':
+        p = dict(cond_stage_params or {})
+        known = {k: p[k] for k in ('vocab_size', 'max_positions', 'width', 'layers', 'heads', 'intermediate', 'ln_eps') if k in p}
+        if 'max_length' in p:
+            known['max_positions'] = int(p['max_length'])
+        return cls(**known)
+
+    def to_c(self) -> _lib.ClipConfigC:
+        c = _lib.ClipConfigC()
+        c.vocab_size, c.max_positions, c.width, c.layers = self.vocab_size, self.max_positions, self.width, self.layers
+        c.heads, c.intermediate, c.ln_eps = self.heads, self.intermediate, self.ln_eps
+        return c
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -126,6 +153,7 @@ class MkdEngine:
             _lib.check(self.lib.mkd_ctx_create(C.byref(cfg.to_c()), C.byref(self._ctx)), 'mkd_ctx_create')
         self._keep: list = []          # tensors the prepared plan points at
         self.vae_cfg: Optional[VaeConfig] = None
+        self.clip_cfg: Optional[ClipConfig] = None
         self._prepared_key = None
         self.batch = 0
         self.latent_hw: Tuple[int, int] = (0, 0)
@@ -177,13 +205,15 @@ class MkdEngine:
             else:
                 unused.append(k)
         missing = [k for k in expected if k not in sd]
-        core_missing = [k for k in missing if not k.startswith('first_stage_model.')]
+        core_missing = [k for k in missing if not k.startswith(('first_stage_model.', 'cond_stage_model.'))]
         if core_missing and strict:
             raise _lib.MkdError(f'{len(core_missing)} weights missing from state_dict, e.g. {core_missing[:3]}')
         if not core_missing:
             self.finalize()
         if getattr(self, 'vae_cfg', None) is not None and not [k for k in missing if k.startswith('first_stage_model.')]:
             self.finalize_vae()
+        if getattr(self, 'clip_cfg', None) is not None and not [k for k in missing if k.startswith('cond_stage_model.')]:
+            self.finalize_clip()
         return unused
 
     def init_random(self, seed: int = 0, gain: float = 1.0) -> None:
@@ -192,7 +222,7 @@ class MkdEngine:
         g = torch.Generator(device=self.device)
         g.manual_seed(seed)
         for name, shape in self.expected_params().items():
-            is_norm = ('.norm' in name or 'in_layers.0' in name or 'out_layers.0' in name
+            is_norm = ('.norm' in name or 'layer_norm' in name or 'in_layers.0' in name or 'out_layers.0' in name
                        or name.endswith('out.0.weight') or name.endswith('out.0.bias'))
             if len(shape) == 1:
                 if is_norm:
@@ -229,6 +259,35 @@ class MkdEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mkd_decode(self._ctx, C.c_void_p(z.data_ptr()), B, h, w, float(scale_factor),
                                            C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), 'mkd_decode')
+        return out
+
+    # ---- CLIP text encoder ----------------------------------------------------------------------------
+    CLIP_PREFIX = 'cond_stage_model.transformer.text_model.'
+
+    def configure_clip(self, ccfg: ClipConfig) -> None:
+        """Adds the cond_stage_model.transformer.text_model.* entries to expected_params(); load them like the rest."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_clip_configure(self._ctx, C.byref(ccfg.to_c())), 'mkd_clip_configure')
+        self.clip_cfg = ccfg
+
+    def finalize_clip(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_clip_finalize(self._ctx), 'mkd_clip_finalize')
+
+    def encode_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
+        """FrozenCLIPEmbedder.forward after tokenisation: ids [B, T<=77] -> last_hidden_state [B, T, width] fp32."""
+        if getattr(self, 'clip_cfg', None) is None:
+            raise _lib.MkdError('text encoder not configured (configure_clip)')
+        if tokens.dim() != 2 or tokens.dtype not in (torch.int32, torch.int64):
+            raise ValueError('tokens must be an integer [B, T] tensor')
+        if tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= self.clip_cfg.vocab_size):
+            raise ValueError(f'token id outside [0, {self.clip_cfg.vocab_size})')      # torch.nn.Embedding raises here too
+        tok = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        B, T = tok.shape
+        out = torch.empty((B, T, self.clip_cfg.width), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_clip_encode(self._ctx, C.c_void_p(tok.data_ptr()), B, T, C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(_stream())), 'mkd_clip_encode')
         return out
 
     def decode_flops(self) -> float:

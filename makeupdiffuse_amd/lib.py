@@ -21,6 +21,11 @@ class VaeConfigC(C.Structure):
                 ('ch_mult', C.c_int32 * 8), ('num_res_blocks', C.c_int32), ('out_ch', C.c_int32)]
 
 
+class ClipConfigC(C.Structure):
+    _fields_ = [('vocab_size', C.c_int32), ('max_positions', C.c_int32), ('width', C.c_int32), ('layers', C.c_int32),
+                ('heads', C.c_int32), ('intermediate', C.c_int32), ('ln_eps', C.c_float)]
+
+
 class NetConfigC(C.Structure):
     _fields_ = [
         ('in_channels', C.c_int32), ('out_channels', C.c_int32), ('hint_channels', C.c_int32),
@@ -57,6 +62,9 @@ SIGNATURES = {
     'mkd_vae_finalize': (_I, [_P]),
     'mkd_decode': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
     'mkd_decode_flops': (C.c_double, [_P]),
+    'mkd_clip_configure': (_I, [_P, C.POINTER(ClipConfigC)]),
+    'mkd_clip_finalize': (_I, [_P]),
+    'mkd_clip_encode': (_I, [_P, _P, _I, _I, _P, _P]),
     'mkd_kind_count': (_I, []),
     'mkd_kind_name': (C.c_char_p, [_I]),
     'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.c_char_p]),
@@ -72,6 +80,7 @@ SIGNATURES = {
     'mkd_groupnorm': (_I, [_P, _I, _P, _P, _F, _I, _P, _I, _I, _I, _I, _I, _P]),
     'mkd_layernorm': (_I, [_P, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    'mkd_attention_causal': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     'mkd_geglu': (_I, [_P, _P, _I, _I, _P]),
     'mkd_conv3x3_direct': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mkd_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),

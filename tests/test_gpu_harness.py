@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_runs_test_py_writes_png_grids_from_a_pair_folder(tmp_path):
+@pytest.mark.parametrize('with_tokenizer', [False, True])
+def test_runs_test_py_writes_png_grids_from_a_pair_folder(tmp_path, with_tokenizer):
     from PIL import Image
     data = tmp_path / 'data'
     os.makedirs(data / 'images' / 'non-makeup'); os.makedirs(data / 'images' / 'makeup')
@@ -19,8 +20,16 @@ def test_runs_test_py_writes_png_grids_from_a_pair_folder(tmp_path):
         Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(data / 'images' / d / n)
     (data / 'test_0412.txt').write_text('non-makeup/s1.png makeup/r1.png\nnon-makeup/s2.png makeup/r2.png\n')
     out = tmp_path / 'out'
+    extra = []
+    if with_tokenizer:       # prompts 'makeup transfer' / '' -> local CLIPTokenizer files -> mkd_clip_encode (synthetic vocabulary)
+        import json
+        words = ['<|startoftext|>', '<|endoftext|>'] + [c + sfx for c in 'makeuptrnsf' for sfx in ('', '</w>')]
+        tk = tmp_path / 'tok'; os.makedirs(tk)
+        (tk / 'vocab.json').write_text(json.dumps({w: i for i, w in enumerate(dict.fromkeys(words))}))
+        (tk / 'merges.txt').write_text('#version: 0.2\n')
+        extra = ['--tokenizer', str(tk)]
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'runs', 'test.py'), '--data-root', str(data), '--res', '64',
-                        '--batch-size', '2', '--ddim-steps', '4', '--out', str(out)],
+                        '--batch-size', '2', '--ddim-steps', '4', '--out', str(out)] + extra,
                        capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     root = out / 'makeupdiffuse_mi355x'
