@@ -81,8 +81,8 @@ struct Op {
     int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
 };
 
-// kinds: [0, 14) conv GEMM by tile config, [14, 28) linear GEMM by tile config, then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 14, K_GROUPNORM = 28, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+// kinds: [0, 17) conv GEMM by tile config, [17, 34) linear GEMM by tile config, then the rest
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 17, K_GROUPNORM = 34, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};

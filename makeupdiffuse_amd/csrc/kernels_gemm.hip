@@ -304,12 +304,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 //   5: 64x64   4 waves (2x2) 4 stages   64 KiB        2 blocks/CU  32
 //   6..11: LDS-staged 3x3 conv tiles (kernels_conv.hip): 256x128, 256x64 (8 waves), 128x128, 128x64, 64x128, 64x64
 //   12: 64x64 6 stages (96 KiB), 13: 64x128 5 stages (120 KiB): short-K layers, (nearly) every K-step in flight at once
-constexpr int N_TILE_CFG = 14;
-static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64};
-static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128};
+//   14: 64x160 3 stages (86 KiB), 15: 128x160 3 stages (110 KiB), 16: 64x160 2 stages (57 KiB, 2 blocks/CU): every channel
+//       count of the nets is a multiple of 320, so 160-wide column tiles never run a partly empty tile (N = 320 -> 2 x 160
+//       instead of 3 x 128 with 17 % of the MFMA work wasted)
+constexpr int N_TILE_CFG = 17;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
-                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5"};
+                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2"};
 static bool is_patch_cfg(int c) { return c >= 6 && c <= 11; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -471,6 +474,9 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         case 4: rc = launch_tile<64, 128, 2, 2, 3>(a, g.splitk, stream); break;
         case 12: rc = launch_tile<64, 64, 2, 2, 6>(a, g.splitk, stream); break;
         case 13: rc = launch_tile<64, 128, 2, 2, 5>(a, g.splitk, stream); break;
+        case 14: rc = launch_tile<64, 160, 2, 2, 3>(a, g.splitk, stream); break;
+        case 15: rc = launch_tile<128, 160, 2, 2, 3>(a, g.splitk, stream); break;
+        case 16: rc = launch_tile<64, 160, 2, 2, 2>(a, g.splitk, stream); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
     }
     if (rc) return rc;

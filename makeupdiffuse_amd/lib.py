@@ -7,7 +7,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmkd.so')
+LIB_PATH = os.environ.get('MKD_LIB_PATH') or os.path.join(HERE, 'libmkd.so')      # override: A/B experiments only
 
 ABI_VERSION = 1
 

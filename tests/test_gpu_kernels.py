@@ -46,7 +46,7 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1)])
 def test_gemm_every_tile_config(cfg, M, N, K, splitk):
     """each gather-GEMM tile / pipeline-depth configuration, incl. K not a multiple of 64 and ragged M/N."""
@@ -143,6 +143,29 @@ def test_gemm_epilogue_variants():
     out = gemm(A, W, bias=bias, ldc=N + 128)
     assert_close_bf16(out[:, :N], base, what='ldc')
     assert (out[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize('cfg', [14, 15, 16])
+@pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up', [(2, 16, 16, 64, 320, 1, 0), (1, 8, 8, 128, 160, 1, 1), (2, 12, 20, 32, 96, 2, 0)])
+def test_gemm_conv3x3_160_wide_tiles(cfg, B, H, W_, Cin, Cout, stride, up):
+    lib = L()
+    g = torch.Generator().manual_seed(cfg + B * H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    xn = xb.permute(0, 2, 3, 1).contiguous()
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(wbf.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    xr = F.interpolate(xb.float(), scale_factor=2, mode='nearest') if up else xb.float()
+    ref = F.conv2d(xr, wbf.float(), bias, stride=stride, padding=1)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        out = gemm(xn, wp, bias=bias, conv=(B, H, W_, Cin, Hout, Wout, stride, up), lda=Cin, splitk=1)
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert_close_bf16(out.float().view(B, Hout, Wout, Cout).permute(0, 3, 1, 2), ref, what=f'conv3x3 cfg {cfg}')
 
 
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up,pad_ld,splitk', [

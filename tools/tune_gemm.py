@@ -22,8 +22,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 
 DEV = 'cuda:0'
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160]
 POOL_BYTES = 640 << 20
 
 
@@ -103,6 +103,8 @@ def main():
     ap.add_argument('--batch', type=int, action='append')
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--out', default='gpurun_out/tune.json')
+    ap.add_argument('--cfgs', default=None, help='comma list: time only these tile configs (merge with earlier sweeps via gen_tuned_table.py); '
+                    'shapes where none beats the HEURISTIC default are skipped')
     ap.add_argument('--vae', action='store_true', help='tune the first-stage decoder shapes instead of the eps plan')
     args = ap.parse_args()
     lib = mlib.load()
@@ -131,7 +133,8 @@ def main():
         t_def = time_cfg(lib, shape, -1, 0, pool, A, out, iters=6 if M * N * K > 4e11 else 12)
         best = (None, None, 1e30)
         trials = []
-        for cfg in range(14):
+        only = [int(c) for c in args.cfgs.split(',')] if args.cfgs else None
+        for cfg in (only if only else range(len(TILE_M))):
             if N % 128 and TILE_N[cfg] == 128 and N < 128:
                 continue
             patch = 6 <= cfg <= 11
@@ -151,6 +154,11 @@ def main():
                 if t < best[2]:
                     best = (cfg, s, t)
         gf = 2.0 * M * N * K / 1e9
+        if only:
+            if best[0] is None or best[2] > 0.97 * t_def:
+                total_best += t_def * count; total_default += t_def * count
+                print(f'[{si + 1}/{len(shapes)}] M={M} N={N} K={K} conv={conv} x{count}: table {t_def:.1f} us stays (best new {best[2]:.1f})', flush=True)
+                continue
         results['_'.join(map(str, shape[:6]))] = {'shape': shape, 'count': count, 'best_cfg': best[0], 'best_splitk': best[1],
                                                   'best_us': best[2], 'default_us': t_def, 'tflops': gf / best[2] * 1e-3,
                                                   'trials': trials}
