@@ -194,6 +194,12 @@ int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ld
                            void* stream);
 /* Tuner / tests only: force the GEMM tile configuration (index into the table in kernels_gemm.hip; -1 = heuristic). */
 int mkd_gemm_force_tile(int cfg);
+/* In-eval tuner (tools/tune_ineval.py): per-shape (tile config, split-K) override consulted before the compiled table;
+ * cfg < 0 removes one entry, M <= 0 clears all.  Takes effect at the next mkd_prepare (plans re-build). */
+int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk);
+/* 1 when tile configuration `cfg` can run this shape (the LDS-staged conv tiles have geometry limits). */
+int mkd_gemm_cfg_supported(int cfg, int M, int N, int K, int conv3x3, int Hin, int Win, int Cin, int Hout, int Wout,
+                           int stride, int up);
 /* GroupNorm(32 groups, fp32 statistics) [+SiLU] over NHWC bf16 (pixel stride ld_in). */
 int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps,
                   int silu, uint16_t* y, int ld_out, int batch, int hw, int C, int groups, void* stream);

@@ -136,6 +136,7 @@ struct mkd_ctx {
     hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
     bool capturing = false;
+    int plan_epoch = 0;
     std::vector<hipEvent_t> aux_ev; int aux_used = 0;        // cross-stream edges inside the decoder (re-used across plan rebuilds)
     std::vector<Op> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
@@ -971,11 +972,12 @@ struct mkd_ctx {
         const bool interp = hint2 != nullptr;
         if (interp && (!ctrl || !alpha)) return mkd_fail(MKD_ERR_ARG, "mkd_prepare_interp: needs hint, hint2 and alpha");
         const bool same = prepared && batch == B && hh == h && ww == w && ctrl == has_control && (only_mid_control != 0) == only_mid &&
-                          interp == has_interp;
+                          interp == has_interp && plan_epoch == gemm_plan_epoch();
         bool same_scales = same;
         for (int i = 0; i < n_ctrl() && same_scales; ++i) same_scales = scales[i] == (control_scales ? control_scales[i] : 1.f);
         in_hint = hint; in_context = context; in_hint2 = hint2; in_alpha = alpha;
         if (!same_scales) {
+            plan_epoch = gemm_plan_epoch();
             B = batch; h = hh; w = ww; has_control = ctrl; only_mid = only_mid_control != 0; has_interp = interp;
             for (int i = 0; i < n_ctrl(); ++i) scales[i] = control_scales ? control_scales[i] : 1.f;
             prepared = false;
@@ -1661,6 +1663,17 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
                        (hipStream_t)stream);
 }
 int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
+int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk) {
+    gemm_set_override(M, N, K, conv3x3, stride, up, cfg, splitk);
+    return 0;
+}
+int mkd_gemm_cfg_supported(int cfg, int M, int N, int K, int conv3x3, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up) {
+    if (cfg < 0 || cfg >= gemm_num_tile_cfgs()) return 0;
+    if (cfg < 6 || cfg > 11) return 1;
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K; a.conv = conv3x3; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
+    return conv_patch_supported(a, cfg) ? 1 : 0;
+}
 int mkd_kind_count(void) { return K_COUNT; }
 const char* mkd_kind_name(int kind) {
     static thread_local std::string nm;

@@ -21,6 +21,8 @@
 //     fp32 partial slabs + a fused reduce/epilogue kernel fills the 256 CUs.
 #include "mkd_common.h"
 #include "gemm_device.h"
+#include <map>
+#include <tuple>
 
 namespace {
 
@@ -330,6 +332,21 @@ static const TunedEntry* tuned_lookup(int M, int N, int K, int conv, int stride,
     return nullptr;
 }
 
+// run-time per-shape overrides (in-eval tuner, tools/tune_ineval.py): consulted before the compiled table
+struct ShapeKey { int M, N, K, conv, stride, up; bool operator<(const ShapeKey& o) const {
+    return std::tie(M, N, K, conv, stride, up) < std::tie(o.M, o.N, o.K, o.conv, o.stride, o.up); } };
+static std::map<ShapeKey, TunedEntry> g_override;
+static int g_plan_epoch = 0;
+int gemm_plan_epoch() { return g_plan_epoch; }
+void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cfg, int splitk) {
+    ++g_plan_epoch;
+    if (M <= 0) { g_override.clear(); return; }
+    const ShapeKey k{M, N, K, conv, stride, up};
+    if (cfg < 0 || cfg >= 17) { g_override.erase(k); return; }
+    TunedEntry e{}; e.M = M; e.N = N; e.K = K; e.conv = conv; e.stride = stride; e.up = up; e.cfg = cfg; e.splitk = splitk < 1 ? 1 : splitk;
+    g_override[k] = e;
+}
+
 static int g_force_cfg = -1;     // tuner / tests only
 static int g_splitk_cap = 0;      // experiment knob (MKD_SPLITK_CAP): 0 = no cap
 void gemm_set_splitk_cap(int cap) { g_splitk_cap = cap; }
@@ -343,6 +360,10 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
     auto tiles = [&](int c) { return ((M + kTileM[c] - 1) / kTileM[c]) * ((N + kTileN[c] - 1) / kTileN[c]); };
     int cfg;
     const TunedEntry* te = (g_force_cfg < 0 && force_splitk <= 0) ? tuned_lookup(M, N, K, conv, stride, up) : nullptr;
+    if (g_force_cfg < 0 && force_splitk <= 0 && !g_override.empty()) {
+        auto it = g_override.find(ShapeKey{M, N, K, conv, stride, up});
+        if (it != g_override.end()) te = &it->second;
+    }
     if (te) {
         GemmPlan g;
         g.cfg = te->cfg;

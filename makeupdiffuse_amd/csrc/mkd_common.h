@@ -85,6 +85,8 @@ int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of th
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
 void gemm_set_splitk_cap(int cap);
+void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cfg, int splitk);   // in-eval tuner; M <= 0 clears all
+int  gemm_plan_epoch();                       // bumped by every override change: launch plans re-build on the next mkd_prepare
 int  gemm_num_tile_cfgs();
 const char* gemm_tile_cfg_name(int cfg);
 int  launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream);
