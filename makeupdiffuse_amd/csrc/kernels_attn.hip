@@ -2,7 +2,9 @@
 // Replaces CrossAttention.forward's einsum / softmax / einsum for attn1 (self,
 // 16..4096 tokens) and attn2 (cross, 77 context tokens), reached from diffmk/makeup_diffuse.py:164-168.
 //
-// One workgroup = 4 wavefronts = 64 queries of one (sample, head); each wave owns 16 queries.
+// One workgroup = NW (4 or 8) wavefronts = 16*NW queries of one (sample, head); each wave owns 16 queries.  Long
+// sequences use NW = 8: every K/V tile fetched from L2 then serves 128 queries (K/V re-reads, not MFMA, bound T >= 1024).
+// The next K/V tile is prefetched into registers while the current one is being consumed.
 // K/V tiles of 64 keys are staged through LDS (K row-major, V transposed so PV's operand is a pair of
 // 8-byte reads).  The score product is computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_16x16x32_bf16)
 // so a lane owns ONE query column: the softmax row-reduction is 15 in-register max/sum ops + two
@@ -27,8 +29,8 @@ struct AttnCfg {
     static constexpr int VBYTES = DVP * VROW;
 };
 
-template <int DH>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                         const bf16_t* __restrict__ K, int ldk,
                                                         const bf16_t* __restrict__ V, int ldv,
                                                         bf16_t* __restrict__ O, int ldo,
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int g = lane >> 4;
     const int bh = blockIdx.y;
     const int b = bh / heads, h = bh - b * heads;
-    const int q0 = blockIdx.x * 64 + w * 16;
+    const int q0 = blockIdx.x * (16 * NW) + w * 16;
     const int qi = q0 + qc;
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[qi][32*ks + 8*g + j]
@@ -71,31 +73,56 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int ntiles = (Tk + KT - 1) / KT;
     const int key_lim = causal ? (qi < Tk ? qi + 1 : Tk) : Tk;      // causal (CLIP text): query i sees keys 0..i; key 0 is always visible
 
+    // staging geometry: chunk = 8 channels (16 B) of one key; thread tid owns chunks tid, tid + 64*NW, ...
+    constexpr int NT = 64 * NW;
+    constexpr int KCHUNKS = KT * (C::DHP / 8), VCHUNKS = KT * (C::DVP / 8);
+    constexpr int KPT = (KCHUNKS + NT - 1) / NT, VPT = (VCHUNKS + NT - 1) / NT;
+    U16x8 kreg[KPT], vreg[VPT];
+    auto prefetch = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
+            U16x8 d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d.v[j] = 0;
+            if (idx < KCHUNKS && key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(kbase + (size_t)(key0 + r) * ldk + c * 8);
+            kreg[i] = d;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + i * NT;
+            const int c = idx / KT, r = idx - c * KT;             // consecutive lanes -> consecutive keys
+            U16x8 d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d.v[j] = 0;
+            if (idx < VCHUNKS && key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(vbase + (size_t)(key0 + r) * ldv + c * 8);
+            vreg[i] = d;
+        }
+    };
+    prefetch(0);
+
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
         __syncthreads();                                   // previous tile fully consumed
-        // ---- stage K tile [64][DHP] row-major (zero padded) ------------------------------------
-        for (int idx = tid; idx < KT * (C::DHP / 8); idx += 256) {
-            const int r = idx / (C::DHP / 8);
-            const int c = idx - r * (C::DHP / 8);
-            U16x8 d;
+        // ---- registers -> LDS: K tile [64][DHP] row-major, V tile transposed vs[d][key] (both zero padded) ----
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d.v[j] = 0;
-            if (key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(kbase + (size_t)(key0 + r) * ldk + c * 8);
-            *(U16x8*)(ks + r * C::KROW + c * 16) = d;
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
+            if (idx < KCHUNKS) *(U16x8*)(ks + r * C::KROW + c * 16) = kreg[i];
         }
-        // ---- stage V tile transposed: vs[d][key] -------------------------------------------------
-        for (int idx = tid; idx < KT * (C::DVP / 8); idx += 256) {
-            const int c = idx / KT;                         // d-chunk (8 values)
-            const int r = idx - c * KT;                     // key: consecutive lanes -> consecutive keys
-            U16x8 d;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d.v[j] = 0;
-            if (key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(vbase + (size_t)(key0 + r) * ldv + c * 8);
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + i * NT;
+            const int c = idx / KT, r = idx - c * KT;
+            if (idx < VCHUNKS) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *(uint16_t*)(vs + (c * 8 + j) * C::VROW + r * 2) = d.v[j];
+                for (int j = 0; j < 8; ++j) *(uint16_t*)(vs + (c * 8 + j) * C::VROW + r * 2) = vreg[i].v[j];
+            }
         }
         __syncthreads();
+        if (t + 1 < ntiles) prefetch(key0 + KT);           // in flight while this tile is consumed
 
         // ---- S^T[key][q] for 4 key blocks of 16 -------------------------------------------------
         f32x4 st[4];
@@ -108,35 +135,47 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                 st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[mf], 0, 0, 0);
             }
         }
-        // lane holds scores of query qc for keys key0 + 16*mf + 4*g + r
+        // lane holds RAW scores of query qc for keys key0 + 16*mf + 4*g + r.  The softmax runs in the log2 domain with the
+        // scale folded into one FMA per score: p = exp2(s*c - m), m = running max of s*c (c = scale*log2(e) > 0).
+        // VALU, not MFMA, bounds this kernel (16 scores per lane per tile), so every per-score op counts: masking only
+        // on a partial / causal tile, raw v_exp_f32, O rescaled only when some row's max moved.
         float mx = -INFINITY;
+        if (causal || key0 + KT > Tk) {
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+            for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + 16 * mf + 4 * g + r;
-                float s = st[mf][r] * scale_log2e;
-                s = key < key_lim ? s : -INFINITY;
-                st[mf][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + 16 * mf + 4 * g + r;
+                    const float s = key < key_lim ? st[mf][r] : -INFINITY;
+                    st[mf][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);              // finite: the first tile always holds a visible key
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        const float m_new = fmaxf(m_run, mx * scale_log2e);   // finite: the first tile always holds a visible key
         float psum = 0.f;
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = exp2f(st[mf][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mf][r], scale_log2e, -m_new));
                 st[mf][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
+        if (__any(m_new != m_run)) {                           // wave-uniform: after the first tiles the max rarely moves
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
+            for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
+        }
+        l_run += psum;
 
         // ---- O^T[d][q] += V^T[d][key'] P^T[key'][q]; key'(g, j) = 32*s + (j<4 ? 4g+j : 16+4g+j-4) -----
 #pragma unroll
@@ -185,12 +224,16 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
                      hipStream_t stream, int causal) {
     if (Tq <= 0 || Tk <= 0 || batch <= 0 || heads <= 0) return mkd_fail(-1, "attention: empty problem");
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
-    dim3 grid((Tq + 63) / 64, batch * heads);
     const float sl = scale * 1.4426950408889634f;
-#define MKD_ATTN_CASE(D)                                                                                   \
-    case D:                                                                                                \
-        hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo, \
-                           Tq, Tk, heads, sl, causal);                                                           \
+    const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
+    const int qb = wide ? 128 : 64;
+    dim3 grid((Tq + qb - 1) / qb, batch * heads);
+#define MKD_ATTN_CASE(D)                                                                                      \
+    case D:                                                                                                   \
+        if (wide) hipLaunchKernelGGL((attention_kernel<D, 8>), grid, dim3(512), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo, \
+                                     Tq, Tk, heads, sl, causal);                                              \
+        else hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo,      \
+                                Tq, Tk, heads, sl, causal);                                                   \
         break;
     switch (dh) {
         MKD_ATTN_CASE(8)
