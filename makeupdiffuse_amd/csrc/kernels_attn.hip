@@ -5,8 +5,8 @@
 // One workgroup = NW (4 or 8) wavefronts = 16*NW queries of one (sample, head); each wave owns 16 queries.  Long
 // sequences use NW = 8: every K/V tile fetched from L2 then serves 128 queries (K/V re-reads, not MFMA, bound T >= 1024).
 // The next K/V tile is prefetched into registers while the current one is being consumed.
-// K/V tiles of 64 keys are staged through LDS (K row-major, V transposed so PV's operand is a pair of
-// 8-byte reads).  The score product is computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_16x16x32_bf16)
+// K/V tiles of 64 keys are staged through LDS, both row-major; PV's V^T operand comes from ds_read_b64_tr_b16, the
+// gfx950 transposing LDS read (no software transpose on the store side).  The score product is computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_16x16x32_bf16)
 // so a lane owns ONE query column: the softmax row-reduction is 15 in-register max/sum ops + two
 // cross-lane shuffles, and S^T's accumulator registers are, after a bf16 pack, directly the B
 // operand of O^T += V^T P^T (k-order permuted identically in both operands) - P never touches LDS.
@@ -16,18 +16,32 @@
 namespace {
 
 constexpr int KT = 64;            // keys per tile
+// MKD_ATTN_TAIL=1 sends the last 8 / 16 channels of dh = 40 / 80 through one 16-deep MFMA (40 padded to 48, not 64): +9 % at
+// 4096 tokens, but the 8-wave build then returns wrong scores (a 16x16x32 result feeding a 16x16x16 SrcC with a different
+// vDst, VGPR form; the 4-wave build keeps the accumulators in AGPRs and is right) -> OFF until that is understood.
+#ifndef MKD_ATTN_TAIL
+#define MKD_ATTN_TAIL 0
+#endif
 
 template <int DH>
 struct AttnCfg {
-    static constexpr int DHP = (DH + 31) / 32 * 32;      // QK^T contraction depth (padded)
-    static constexpr int KS = DHP / 32;                  // k-steps of QK^T
+    static constexpr int TAIL = (MKD_ATTN_TAIL && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
+    static constexpr int KS = TAIL ? DH / 32 : (DH + 31) / 32;          // 32-deep k-steps of QK^T
+    static constexpr int DHP = 32 * KS + 16 * TAIL;      // QK^T contraction depth, zero padded (40 -> 48, not 64)
     static constexpr int DVP = (DH + 15) / 16 * 16;      // output rows of O^T (padded)
     static constexpr int MD = DVP / 16;                  // O^T fragments
     static constexpr int KROW = DHP * 2 + 16;            // K tile row stride in bytes (pad: bank spread)
-    static constexpr int VROW = KT * 2 + 8;              // V^T tile row stride in bytes
+    // V tile stays ROW-MAJOR [key][d] and is read transposed by ds_read_b64_tr_b16 (gfx950).  A 32-lane half reads 8
+    // consecutive key rows x 4 column quads: conflict-free when the row stride in dwords is 8 * odd.
+    static constexpr int VR0 = DVP / 2;
+    static constexpr int VROW = 4 * (VR0 + ((8 - VR0 % 16) + 16) % 16);
     static constexpr int KBYTES = KT * KROW;
-    static constexpr int VBYTES = DVP * VROW;
+    static constexpr int VBYTES = KT * VROW;
+    static_assert(DH % 8 == 0 && (!TAIL || DH % 32 <= 16), "head dim: multiple of 8 (tail of at most 16 past the 32-deep steps)");
 };
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
@@ -48,18 +62,26 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
     const int q0 = blockIdx.x * (16 * NW) + w * 16;
     const int qi = q0 + qc;
 
-    // Q fragments (B operand of S^T = K Q^T): lane holds Q[qi][32*ks + 8*g + j]
-    bf16x8 qf[C::KS];
+    // Q fragments (B operand of S^T = K Q^T): lane holds Q[qi][32*s + 8*g + j]; tail step: Q[qi][32*KS + 4*g + j]
+    bf16x8 qf[C::KS ? C::KS : 1];
+    bf16x4v qt = {0, 0, 0, 0};
     {
         const bf16_t* qrow = Q + ((size_t)b * Tq + (qi < Tq ? qi : 0)) * ldq + h * DH;
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-            const int d = 32 * s + 8 * g;
             U16x8 t;
 #pragma unroll
             for (int j = 0; j < 8; ++j) t.v[j] = 0;
-            if (qi < Tq && d < DH) t = *(const U16x8*)(qrow + d);
+            if (qi < Tq && 32 * s + 8 * g < DH) t = *(const U16x8*)(qrow + 32 * s + 8 * g);
             qf[s] = __builtin_bit_cast(bf16x8, t);
+        }
+        if (C::TAIL) {
+            const int d = 32 * C::KS + 4 * g;
+            U16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.v[j] = 0;
+            if (qi < Tq && d < DH) t = *(const U16x4*)(qrow + d);
+            qt = __builtin_bit_cast(bf16x4v, t);
         }
     }
 
@@ -92,7 +114,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = tid + i * NT;
-            const int c = idx / KT, r = idx - c * KT;             // consecutive lanes -> consecutive keys
+            const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
             U16x8 d;
 #pragma unroll
             for (int j = 0; j < 8; ++j) d.v[j] = 0;
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
         __syncthreads();                                   // previous tile fully consumed
-        // ---- registers -> LDS: K tile [64][DHP] row-major, V tile transposed vs[d][key] (both zero padded) ----
+        // ---- registers -> LDS: K tile [64][DHP] and V tile [64][DVP], both row-major and zero padded ----
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + i * NT;
@@ -115,11 +137,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = tid + i * NT;
-            const int c = idx / KT, r = idx - c * KT;
-            if (idx < VCHUNKS) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *(uint16_t*)(vs + (c * 8 + j) * C::VROW + r * 2) = vreg[i].v[j];
-            }
+            const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
+            if (idx < VCHUNKS) *(U16x8*)(vs + r * C::VROW + c * 16) = vreg[i];
         }
         __syncthreads();
         if (t + 1 < ntiles) prefetch(key0 + KT);           // in flight while this tile is consumed
@@ -129,10 +148,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* krow = ks + (16 * mf + qc) * C::KROW;
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) {
-                const bf16x8 kf = *(const bf16x8*)(ks + (16 * mf + qc) * C::KROW + (32 * s + 8 * g) * 2);
+                const bf16x8 kf = *(const bf16x8*)(krow + (32 * s + 8 * g) * 2);
                 st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[mf], 0, 0, 0);
+            }
+            if (C::TAIL) {
+                const bf16x4v kt = *(const bf16x4v*)(krow + (32 * C::KS + 4 * g) * 2);
+                st[mf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kt), __builtin_bit_cast(s16x4, qt), st[mf], 0, 0, 0);
             }
         }
         // lane holds RAW scores of query qc for keys key0 + 16*mf + 4*g + r.  The softmax runs in the log2 domain with the
@@ -186,15 +210,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
                 pf[j] = (__bf16)st[2 * s][j];
                 pf[4 + j] = (__bf16)st[2 * s + 1][j];
             }
+            // V^T fragment through the hardware transpose read: a 16-lane group fetches a 4-key x 16-channel block and
+            // lane i receives channel 16*md + i of those 4 keys (lane 4q + p supplies the address of key row q, quad p)
+            const char* vblk = vs + (32 * s + 4 * g + (qc >> 2)) * C::VROW + (qc & 3) * 8;
 #pragma unroll
             for (int md = 0; md < C::MD; ++md) {
-                const char* vrow = vs + (16 * md + qc) * C::VROW;
-                const bf16x4 lo = *(const bf16x4*)(vrow + (32 * s + 4 * g) * 2);
-                const bf16x4 hi = *(const bf16x4*)(vrow + (32 * s + 16 + 4 * g) * 2);
-                bf16x8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                oacc[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[md], 0, 0, 0);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + md * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + 16 * C::VROW + md * 32));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[md], 0, 0, 0);
             }
         }
     }
