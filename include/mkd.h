@@ -194,6 +194,9 @@ int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ld
                            void* stream);
 /* Tuner / tests only: force the GEMM tile configuration (index into the table in kernels_gemm.hip; -1 = heuristic). */
 int mkd_gemm_force_tile(int cfg);
+/* Tests only (race detector): overwrite every buffer one mkd_eps produces (activations, temporaries, workspaces) with NaN
+ * patterns, so that a kernel running ahead of its producer cannot see the previous call's values.  Synchronous. */
+int mkd_debug_poison(mkd_ctx* ctx);
 /* In-eval tuner (tools/tune_ineval.py): per-shape (tile config, split-K) override consulted before the compiled table;
  * cfg < 0 removes one entry, M <= 0 clears all.  Takes effect at the next mkd_prepare (plans re-build). */
 int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk);

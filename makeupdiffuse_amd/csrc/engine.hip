@@ -125,18 +125,27 @@ struct mkd_ctx {
     bool has_control = false, only_mid = false;
     float scales[64];
     int n_ctrl() const { return (int)encoder_spec().size() + 1; }
-    Arena persist, temp_arena[2];
+    static constexpr int NS = 4;              // streams / temp arenas: 0 = caller's stream, 1..3 = side streams
+    static constexpr int SID_HELPER = 8;      // decoder helper GEMMs: side stream 1 unless capturing (arena 1)
+    Arena persist, temp_arena[NS];
     int cur_sid = 0;
-    Arena& TA() { return temp_arena[cur_sid ? 1 : 0]; }      // sid 0 main, 1 side (ControlNet), 2 decoder helpers: side unless capturing
-    char* persist_base = nullptr; char* temp_base[2] = {nullptr, nullptr};
-    size_t persist_cap = 0, temp_cap[2] = {0, 0};
-    float* splitk_ws[2] = {nullptr, nullptr}; size_t splitk_ws_bytes[2] = {0, 0}, splitk_need = 0;
-    float* gn_ws[2] = {nullptr, nullptr}; size_t gn_ws_bytes[2] = {0, 0}, gn_need = 0;
-    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static int arena_of(int sid) { return sid == SID_HELPER ? 1 : sid; }
+    Arena& TA() { return temp_arena[arena_of(cur_sid)]; }
+    char* persist_base = nullptr; char* temp_base[NS] = {};
+    size_t persist_cap = 0, temp_cap[NS] = {};
+    float* splitk_ws[NS] = {}; size_t splitk_ws_bytes[NS] = {}, splitk_need = 0;
+    float* gn_ws[NS] = {}; size_t gn_ws_bytes[NS] = {}, gn_need = 0;
+    hipStream_t side_streams[NS] = {};        // [0] unused (the caller's stream)
+    hipStream_t stream_of(int sid) const { return (sid == 0 || run_serial) ? run_main : side_streams[sid == SID_HELPER ? 1 : sid]; }
     hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
+    // measured at batch 8, 256x256 (ms per evaluation): no lanes 6.78, 2 decoder lanes 6.58, 4 decoder lanes 6.89, encoder lanes
+    // on top +0.25: the encoder phase already runs two nets side by side, a third and fourth stream only add contention
+    int dec_lanes = getenv("MKD_DEC_LANES") ? atoi(getenv("MKD_DEC_LANES")) : 2;          // 0 / 2 / 4 half- or quarter-batch decoder lanes
+    bool enc_lanes = getenv("MKD_ENC_LANES") ? atoi(getenv("MKD_ENC_LANES")) != 0 : false;
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
     bool capturing = false;
     int plan_epoch = 0;
+    size_t persist_eps_begin = 0;
     std::vector<hipEvent_t> aux_ev; int aux_used = 0;        // cross-stream edges inside the decoder (re-used across plan rebuilds)
     std::vector<Op> plan_prepare, plan_eps;
     double flops_eps = 0; int launches_eps = 0;
@@ -529,7 +538,7 @@ struct mkd_ctx {
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
         const int sid = cur_sid;
-        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[sid ? 1 : 0]; return launch_gemm(b, st); },
+        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[arena_of(sid)]; return launch_gemm(b, st); },
              s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
              (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0),
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
@@ -563,7 +572,7 @@ struct mkd_ctx {
         Tensor t = in;
         const int sid = cur_sid;
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out, sid](hipStream_t st) {
-            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[sid ? 1 : 0], st);
+            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[arena_of(sid)], st);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
@@ -595,7 +604,7 @@ struct mkd_ctx {
         if (x.C != cout && side_skip) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
             op_edge(0, 1);                               // side waits for the block input (written on main)
-            cur_sid = dec_overlap ? 2 : 0;
+            cur_sid = dec_overlap ? SID_HELPER : 0;
             Epi es; es.bias = wf(p + ".skip_connection.bias");
             op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
             cur_sid = 0;
@@ -624,7 +633,9 @@ struct mkd_ctx {
     }
 
     // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
-    void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo) {
+    // b0: first sample of x inside the prepared batch (decoder lanes run on a batch slice; the cross-attention K/V cache is
+    // indexed by absolute sample)
+    void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo, int b0 = 0) {
         const size_t mk = TA().mark();
         const int d = x.C, M = x.rows(), T = x.H * x.W, heads = cfg.num_heads, dh = d / heads;
         const std::string t = p + ".transformer_blocks.0";
@@ -661,7 +672,8 @@ struct mkd_ctx {
         { Epi e; const bf16_t* a_in = ln_input(h1, ".norm2");
           if (fl) { e.bias = q2_b.at(p); e.ln_s = q2_s.at(p); e.stat_in = st1; e.stat_slots = slots; }
           op_linear(a_in, d, M, d, fl ? q2_w.at(p) : wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
-        const Tensor& kv = kv_cache.at(p);
+        Tensor kv = kv_cache.at(p);
+        kv.p += (size_t)b0 * ctx_len() * kv.ld;
         bf16_t* a2 = buf(d);
         op_attn(q2, d, kv.p, 2 * d, kv.p + d, 2 * d, a2, d, x.B, T, ctx_len(), heads, dh);
         bf16_t* h2 = buf(d);
@@ -699,55 +711,64 @@ struct mkd_ctx {
         return proj;
     }
 
-    // encoder + middle block of one net. feats[i] = output of input_blocks[i]; returns middle output.
-    Tensor encoder(int which, const float* embproj, std::vector<Tensor>& feats) {
+    static Tensor slice(Tensor t, int b0, int nb) { t.p += (size_t)b0 * t.H * t.W * t.ld; t.B = nb; return t; }
+
+    // whole-batch outputs of one net's encoder: feats[i] = output of input_blocks[i]; mid = middle block output
+    void alloc_encoder(std::vector<Tensor>& feats, Tensor& mid) {
+        auto enc = encoder_spec();
+        int H = h, W = w;
+        for (size_t i = 0; i < enc.size(); ++i) {
+            if (enc[i].kind == 2) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
+            feats.push_back(talloc(persist, B, H, W, enc[i].cout));
+        }
+        mid = talloc(persist, B, H, W, enc.back().cout);
+    }
+
+    // encoder + middle block of one net over samples [b0, b0 + nb) (every op is per-sample, so a batch slice is a valid lane)
+    void encoder_lane(int which, const float* embproj_all, const std::vector<Tensor>& feats, const Tensor& mid, int b0, int nb) {
         const std::string P = net_prefix(which);
         auto enc = encoder_spec();
         const int ld_emb = emb_total[which];
+        const float* embproj = embproj_all + (size_t)b0 * ld_emb;
         mkd_ctx* self = this;
         Tensor hcur;
         for (size_t i = 0; i < enc.size(); ++i) {
             const BlockSpec& b = enc[i];
             const std::string p = P + "input_blocks." + std::to_string(i);
+            const Tensor o = slice(feats[i], b0, nb);
             if (b.kind == 0) {
-                Tensor o = talloc(persist, B, h, w, b.cout);
                 const bf16_t* wgt = wb(p + ".0.weight"); const float* bias = wf(p + ".0.bias");
-                const bf16_t* add = which == 1 ? hint_emb.p : nullptr;
-                const int Bn = B, hh = h, ww = w, cin = b.cin, cout = b.cout;
-                push(*cur_plan, [self, wgt, bias, o, add, Bn, hh, ww, cin, cout](hipStream_t st) {
-                    return launch_conv3x3_direct(self->io_x, 1, wgt, bias, o.p, 0, 0, add, Bn, hh, ww, cin, cout, 1, st);
-                }, 1, 2.0 * B * h * w * b.cout * 9 * b.cin, K_CONV_DIRECT);
-                hcur = o;
+                const bf16_t* add = which == 1 ? slice(hint_emb, b0, nb).p : nullptr;
+                const int hh = h, ww = w, cin = b.cin, cout = b.cout;
+                const size_t xoff = (size_t)b0 * cin * hh * ww;
+                push(*cur_plan, [self, wgt, bias, o, add, nb, hh, ww, cin, cout, xoff](hipStream_t st) {
+                    return launch_conv3x3_direct(self->io_x + xoff, 1, wgt, bias, o.p, 0, 0, add, nb, hh, ww, cin, cout, 1, st);
+                }, 1, 2.0 * nb * h * w * b.cout * 9 * b.cin, K_CONV_DIRECT);
             } else if (b.kind == 1) {
-                Tensor o = talloc(persist, hcur.B, hcur.H, hcur.W, b.cout);
                 if (b.attn) {
                     const size_t mk = TA().mark();
                     Tensor r = talloc(TA(), hcur.B, hcur.H, hcur.W, b.cout);
                     resblock(p + ".0", hcur, b.cout, embproj, ld_emb, r.p, r.ld);
-                    spatial_transformer(p + ".1", r, o.p, o.ld);
+                    spatial_transformer(p + ".1", r, o.p, o.ld, b0);
                     TA().release(mk);
                 } else {
                     resblock(p + ".0", hcur, b.cout, embproj, ld_emb, o.p, o.ld);
                 }
-                hcur = o;
             } else {
-                Tensor o = talloc(persist, hcur.B, (hcur.H - 1) / 2 + 1, (hcur.W - 1) / 2 + 1, b.cout);
                 Epi e; e.bias = wf(p + ".0.op.bias");
                 op_conv(hcur, wb(p + ".0.op.weight"), b.cout, 2, 0, e, o.p, o.ld);
-                hcur = o;
             }
-            feats.push_back(hcur);
+            hcur = o;
         }
         const int ch = hcur.C;
         const size_t mk = TA().mark();
         Tensor m1 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
         resblock(P + "middle_block.0", hcur, ch, embproj, ld_emb, m1.p, m1.ld);
         Tensor m2 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
-        spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld);
-        Tensor m3 = talloc(persist, hcur.B, hcur.H, hcur.W, ch);
+        spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld, b0);
+        const Tensor m3 = slice(mid, b0, nb);
         resblock(P + "middle_block.2", m2, ch, embproj, ld_emb, m3.p, m3.ld);
         TA().release(mk);
-        return m3;
     }
 
     void build_prepare_plan() {
@@ -822,134 +843,157 @@ struct mkd_ctx {
         mkd_ctx* self = this;
         std::vector<Tensor> cn_feats, hs;
         Tensor cn_mid, u_mid;
-        // The ControlNet and the UNet encoder+middle only meet at the zero-conv "combine": build them as two
-        // op lists, run the ControlNet on the side stream and interleave the enqueue order so both streams
-        // are fed from the first launch on.
-        std::vector<Op> ops_cn, ops_ue;
-        float* ep0 = nullptr;
-        if (has_control) {
-            cur_plan = &ops_cn; cur_sid = 1;
-            float* ep = time_embedding(1);
-            cn_mid = encoder(1, ep, cn_feats);
+        // The ControlNet and the UNet encoder+middle only meet at the zero-conv "combine", and every op is per-sample: the two
+        // nets run on different streams, each optionally as two half-batch lanes (UNet lanes on streams 0 / 2, ControlNet lanes
+        // on 1 / 3), with the host enqueue order interleaved so all streams are fed from the first launch on.  These kernels are
+        // latency-bound (a batch-2 evaluation takes 60 % of a batch-8 one), so concurrency is what pays.
+        const int EL = (enc_lanes && B >= 2) ? 2 : 1;
+        float* ep0 = nullptr; float* ep1 = nullptr;
+        cur_plan = &plan_eps;
+        if (has_control) op_edge(0, 1, true, true);      // side stream starts after everything already enqueued by the caller
+        cur_sid = 0; ep0 = time_embedding(0);
+        if (has_control) { cur_sid = 1; ep1 = time_embedding(1); }
+        if (EL == 2) { op_edge(0, 2, true, true); if (has_control) op_edge(1, 3, true, true); }
+        alloc_encoder(hs, u_mid);
+        if (has_control) alloc_encoder(cn_feats, cn_mid);
+        std::vector<Op> lists[NS];
+        for (int l = 0; l < EL; ++l) {
+            const int nb0 = EL == 2 ? B / 2 : B;
+            const int b0 = l ? nb0 : 0, nb = l ? B - nb0 : nb0;
+            if (has_control) { cur_plan = &lists[2 * l + 1]; cur_sid = 2 * l + 1; encoder_lane(1, ep1, cn_feats, cn_mid, b0, nb); }
+            cur_plan = &lists[2 * l]; cur_sid = 2 * l; encoder_lane(0, ep0, hs, u_mid, b0, nb);
         }
-        cur_plan = &ops_ue; cur_sid = 0;
-        ep0 = time_embedding(0);
-        u_mid = encoder(0, ep0, hs);
         cur_plan = &plan_eps; cur_sid = 0;
-        if (!dry) {
-            if (has_control) {
-                Op f; f.kind = K_MISC; f.label = "fork";
-                f.fn = [self](hipStream_t) { return self->fork_side(); };
-                plan_eps.push_back(std::move(f));
-            }
-            size_t a = 0, b2 = 0;
-            while (a < ops_cn.size() || b2 < ops_ue.size()) {
-                if (a < ops_cn.size()) plan_eps.push_back(std::move(ops_cn[a++]));
-                if (b2 < ops_ue.size()) plan_eps.push_back(std::move(ops_ue[b2++]));
-            }
-            if (has_control) {
-                Op j; j.kind = K_MISC; j.label = "join";
-                j.fn = [self](hipStream_t) { return self->join_side(); };
-                plan_eps.push_back(std::move(j));
+        {
+            size_t idx[NS] = {};
+            for (bool more = true; more;) {
+                more = false;
+                for (int k : {1, 0, 3, 2})
+                    if (idx[k] < lists[k].size()) { plan_eps.push_back(std::move(lists[k][idx[k]++])); more = true; }
             }
         }
+        for (int k = 1; k < NS; ++k)
+            if (!lists[k].empty()) op_edge(k, 0, true, true);      // join: the decoder needs every encoder lane
 
         auto dec = decoder_spec();
         const std::string P = net_prefix(0), PC = net_prefix(1);
         // Concat buffers of all decoder blocks: [h (from the previous block / mid) | skip (+ control residual)].
-        // The "combine" GEMMs that fill the skip halves (zero-conv * scale + UNet skip) only depend on the two encoders,
-        // so they run on the side stream AHEAD of the decoder, interleaved with the blocks' 1x1 skip GEMMs; the main
-        // stream waits per block on an event.
         int n_skip = (int)hs.size();
         std::vector<Tensor> cats(dec.size());
+        Tensor final_t;
         {
             int Hc = hs[n_skip - 1].H, Wc = hs[n_skip - 1].W;
             for (size_t i = 0; i < dec.size(); ++i) {
                 cats[i] = talloc(persist, B, Hc, Wc, dec[i].cin);
                 if (dec[i].up) { Hc *= 2; Wc *= 2; }
             }
+            final_t = talloc(persist, B, Hc, Wc, dec.back().cout);
         }
-        auto combine = [&](size_t i) {          // emits on the CURRENT sid
-            const BlockSpec& b = dec[i];
-            const int si = n_skip - 1 - (int)i;
-            const Tensor& skip = hs[si];
-            const int ch_h = b.cin - skip.C;
-            Tensor& cat = cats[i];
-            if (i == 0) {
-                if (has_control) {
-                    Epi e; e.bias = wf(PC + "middle_block_out.0.bias"); e.scale = scales[n_ctrl() - 1]; e.R = u_mid.p; e.ldr = u_mid.ld;
-                    op_linear(cn_mid.p, cn_mid.ld, cn_mid.rows(), cn_mid.C, wb(PC + "middle_block_out.0.weight"), cn_mid.C, e, cat.p, cat.ld);
-                } else {
-                    op_copy(u_mid.p, u_mid.ld, cat.p, cat.ld, u_mid.rows(), u_mid.C);
+        // One decoder pass over samples [b0, b0 + nb).  helpers_on_side: the zero-conv "combine" GEMMs (skip + scale *
+        // zero_conv(cn_feat), written straight into the concat buffer's skip half) and the ResBlocks' 1x1 skip GEMMs only depend
+        // on the encoders / the block input, so they run on the side stream under the main GN -> conv -> GN chain.
+        auto emit_decoder = [&](int b0, int nb, bool helpers_on_side) {
+            const int main_sid = cur_sid;
+            const int help_sid = helpers_on_side ? SID_HELPER : main_sid;
+            auto combine = [&](size_t i) {          // emits on the CURRENT sid
+                const BlockSpec& bs = dec[i];
+                const int si = n_skip - 1 - (int)i;
+                const Tensor skip = slice(hs[si], b0, nb);
+                const int ch_h = bs.cin - skip.C;
+                const Tensor cat = slice(cats[i], b0, nb);
+                if (i == 0) {
+                    const Tensor um = slice(u_mid, b0, nb);
+                    if (has_control) {
+                        const Tensor cm = slice(cn_mid, b0, nb);
+                        Epi e; e.bias = wf(PC + "middle_block_out.0.bias"); e.scale = scales[n_ctrl() - 1]; e.R = um.p; e.ldr = um.ld;
+                        op_linear(cm.p, cm.ld, cm.rows(), cm.C, wb(PC + "middle_block_out.0.weight"), cm.C, e, cat.p, cat.ld);
+                    } else {
+                        op_copy(um.p, um.ld, cat.p, cat.ld, um.rows(), um.C);
+                    }
                 }
+                if (has_control && !only_mid) {
+                    const Tensor cf = slice(cn_feats[si], b0, nb);
+                    Epi e; e.bias = wf(PC + "zero_convs." + std::to_string(si) + ".0.bias"); e.scale = scales[si]; e.R = skip.p; e.ldr = skip.ld;
+                    op_linear(cf.p, cf.ld, cf.rows(), cf.C, wb(PC + "zero_convs." + std::to_string(si) + ".0.weight"), cf.C, e, cat.p + ch_h, cat.ld);
+                } else {
+                    op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
+                }
+            };
+            if (helpers_on_side) op_edge(0, 1);     // side: both encoders are complete (main already joined the ControlNet)
+            cur_sid = help_sid; combine(0); cur_sid = main_sid;
+            Tensor cat;
+            for (size_t i = 0; i < dec.size(); ++i) {
+                const BlockSpec& bs = dec[i];
+                cat = slice(cats[i], b0, nb);
+                if (helpers_on_side) op_edge(1, 0);  // main: this block's concat input is complete
+                if (i + 1 < dec.size()) { cur_sid = help_sid; combine(i + 1); cur_sid = main_sid; }   // next block's combine runs under this block
+                // where does this block's output go?  next concat buffer's h half (or the final tensor)
+                const std::string p = P + "output_blocks." + std::to_string(i);
+                const Tensor nxt = slice(i + 1 < dec.size() ? cats[i + 1] : final_t, b0, nb);
+                bf16_t* dst = nxt.p; const int dst_ld = nxt.ld;
+                const size_t mk = TA().mark();
+                const int stages = 1 + (bs.attn ? 1 : 0) + (bs.up ? 1 : 0);
+                Tensor cur_in = cat;
+                int stage = 0;
+                {   // ResBlock
+                    ++stage;
+                    bf16_t* op_; int ol;
+                    if (stage == stages) { op_ = dst; ol = dst_ld; }
+                    else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout); op_ = o.p; ol = o.ld; }
+                    resblock(p + ".0", cur_in, bs.cout, ep0 + (size_t)b0 * emb_total[0], emb_total[0], op_, ol, /*side_skip=*/helpers_on_side);
+                    cur_in.p = op_; cur_in.C = bs.cout; cur_in.ld = ol;
+                }
+                if (bs.attn) {
+                    ++stage;
+                    bf16_t* op_; int ol;
+                    if (stage == stages) { op_ = dst; ol = dst_ld; }
+                    else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout); op_ = o.p; ol = o.ld; }
+                    spatial_transformer(p + ".1", cur_in, op_, ol, b0);
+                    cur_in.p = op_; cur_in.ld = ol;
+                }
+                if (bs.up) {
+                    const int k = bs.attn ? 2 : 1;
+                    Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias");
+                    op_conv(cur_in, wb(p + "." + std::to_string(k) + ".conv.weight"), bs.cout, 1, 1, e, dst, dst_ld);
+                }
+                TA().release(mk);
             }
-            if (has_control && !only_mid) {
-                const Tensor& cf = cn_feats[si];
-                Epi e; e.bias = wf(PC + "zero_convs." + std::to_string(si) + ".0.bias"); e.scale = scales[si]; e.R = skip.p; e.ldr = skip.ld;
-                op_linear(cf.p, cf.ld, cf.rows(), cf.C, wb(PC + "zero_convs." + std::to_string(si) + ".0.weight"), cf.C, e, cat.p + ch_h, cat.ld);
-            } else {
-                op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
+            // out: GN32 + SiLU + conv3x3 C -> out_channels (fp32 NCHW)
+            {
+                const Tensor fin = slice(final_t, b0, nb);
+                const size_t mk = TA().mark();
+                Tensor g = talloc(TA(), fin.B, fin.H, fin.W, fin.C);
+                op_gn(fin, wf(P + "out.0.weight"), wf(P + "out.0.bias"), 1e-5f, 1, g.p, g.ld);
+                const bf16_t* wgt = wb(P + "out.2.weight"); const float* bias = wf(P + "out.2.bias");
+                const int hh = h, ww = w, cin = fin.C, cout = cfg.out_channels;
+                const size_t out_off = (size_t)b0 * cout * hh * ww;
+                push(*cur_plan, [self, g, wgt, bias, nb, hh, ww, cin, cout, out_off](hipStream_t st) {
+                    return launch_conv3x3_direct(g.p, 0, wgt, bias, self->io_out + out_off, 1, 0, nullptr, nb, hh, ww, cin, cout, 1, st);
+                }, 1, 2.0 * nb * h * w * cfg.out_channels * 9 * fin.C, K_CONV_DIRECT);
+                TA().release(mk);
             }
         };
-        op_edge(0, 1);                          // side: both encoders are complete (main already joined the ControlNet)
-        cur_sid = dec_overlap ? 2 : 0; combine(0); cur_sid = 0;
-        Tensor cat;
-        for (size_t i = 0; i < dec.size(); ++i) {
-            const BlockSpec& b = dec[i];
-            cat = cats[i];
-            op_edge(1, 0);                      // main: this block's concat input is complete
-            if (i + 1 < dec.size()) { cur_sid = dec_overlap ? 2 : 0; combine(i + 1); cur_sid = 0; }      // next block's combine runs under this block
-            // where does this block's output go?  next concat buffer's h half (or the final tensor)
-            const std::string p = P + "output_blocks." + std::to_string(i);
-            Tensor nxt_cat; bf16_t* dst; int dst_ld;
-            const int outH = b.up ? cat.H * 2 : cat.H, outW = b.up ? cat.W * 2 : cat.W;
-            if (i + 1 < dec.size()) {
-                nxt_cat = cats[i + 1];
-                dst = nxt_cat.p; dst_ld = nxt_cat.ld;
-            } else {
-                nxt_cat = talloc(persist, cat.B, outH, outW, b.cout);
-                dst = nxt_cat.p; dst_ld = nxt_cat.ld;
+        const int DL = (dec_lanes >= 4 && B >= 4) ? 4 : ((dec_lanes >= 2 && B >= 2) ? 2 : 1);
+        if (DL > 1) {
+            // Batch-slice lanes: every op is per-sample, so lane l decodes its share of the samples on stream l, host enqueue
+            // interleaved.  Also inside a hipGraph capture (one fork / join edge per extra lane).
+            std::vector<Op> lane_ops[NS];
+            for (int l = 0; l < DL; ++l) {
+                const int b0 = (int)((int64_t)B * l / DL), b1 = (int)((int64_t)B * (l + 1) / DL);
+                cur_plan = &lane_ops[l]; cur_sid = l;
+                emit_decoder(b0, b1 - b0, false);
             }
-            const size_t mk = TA().mark();
-            const int stages = 1 + (b.attn ? 1 : 0) + (b.up ? 1 : 0);
-            Tensor cur_in = cat;
-            int stage = 0;
-            // ResBlock
-            {
-                ++stage;
-                Tensor o; bf16_t* op_; int ol;
-                if (stage == stages) { op_ = dst; ol = dst_ld; o.p = dst; }
-                else { o = talloc(TA(), cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
-                resblock(p + ".0", cur_in, b.cout, ep0, emb_total[0], op_, ol, /*side_skip=*/true);
-                cur_in.p = op_; cur_in.C = b.cout; cur_in.ld = ol;
+            cur_plan = &plan_eps; cur_sid = 0;
+            for (int l = 1; l < DL; ++l) op_edge(0, l, true, true);     // lanes start after the encoders (all joined on main)
+            size_t idx[NS] = {};
+            for (bool more = true; more;) {
+                more = false;
+                for (int l = 0; l < DL; ++l)
+                    if (idx[l] < lane_ops[l].size()) { plan_eps.push_back(std::move(lane_ops[l][idx[l]++])); more = true; }
             }
-            if (b.attn) {
-                ++stage;
-                bf16_t* op_; int ol;
-                if (stage == stages) { op_ = dst; ol = dst_ld; }
-                else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, b.cout); op_ = o.p; ol = o.ld; }
-                spatial_transformer(p + ".1", cur_in, op_, ol);
-                cur_in.p = op_; cur_in.ld = ol;
-            }
-            if (b.up) {
-                const int k = b.attn ? 2 : 1;
-                Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias");
-                op_conv(cur_in, wb(p + "." + std::to_string(k) + ".conv.weight"), b.cout, 1, 1, e, dst, dst_ld);
-            }
-            TA().release(mk);
-            cat = nxt_cat;
-        }
-        // out: GN32 + SiLU + conv3x3 C -> out_channels (fp32 NCHW)
-        {
-            const size_t mk = TA().mark();
-            Tensor g = talloc(TA(), cat.B, cat.H, cat.W, cat.C);
-            op_gn(cat, wf(P + "out.0.weight"), wf(P + "out.0.bias"), 1e-5f, 1, g.p, g.ld);
-            const bf16_t* wgt = wb(P + "out.2.weight"); const float* bias = wf(P + "out.2.bias");
-            const int Bn = B, hh = h, ww = w, cin = cat.C, cout = cfg.out_channels;
-            push(*cur_plan, [self, g, wgt, bias, Bn, hh, ww, cin, cout](hipStream_t st) {
-                return launch_conv3x3_direct(g.p, 0, wgt, bias, self->io_out, 1, 0, nullptr, Bn, hh, ww, cin, cout, 1, st);
-            }, 1, 2.0 * B * h * w * cfg.out_channels * 9 * cat.C, K_CONV_DIRECT);
-            TA().release(mk);
+            for (int l = 1; l < DL; ++l) op_edge(l, 0, true, true);     // the evaluation ends when every lane has
+        } else {
+            emit_decoder(0, B, dec_overlap);
         }
         counting_eps = false;
     }
@@ -984,28 +1028,27 @@ struct mkd_ctx {
             // pass 1: dry run to size the arenas (pointers are offsets from null and never dereferenced)
             dry = true;
             persist.base = nullptr; persist.reset();
-            for (int i = 0; i < 2; ++i) { temp_arena[i].base = nullptr; temp_arena[i].reset(); }
+            for (int i = 0; i < NS; ++i) { temp_arena[i].base = nullptr; temp_arena[i].reset(); }
             splitk_need = 0; gn_need = 0;
             plan_prepare.clear(); plan_eps.clear();
             cur_sid = 0;
             build_prepare_plan(); build_eps_plan();
             int rc = ensure((void**)&persist_base, &persist_cap, persist.high + 256); if (rc) return rc;
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NS; ++i) {
                 rc = ensure((void**)&temp_base[i], &temp_cap[i], temp_arena[i].high + 256); if (rc) return rc;
                 rc = ensure((void**)&splitk_ws[i], &splitk_ws_bytes[i], splitk_need); if (rc) return rc;
                 rc = ensure((void**)&gn_ws[i], &gn_ws_bytes[i], gn_need); if (rc) return rc;
             }
-            if (!side_stream) {
-                MKD_HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                MKD_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-            }
+            for (int i = 1; i < NS; ++i)
+                if (!side_streams[i]) MKD_HIP_CHECK(hipStreamCreateWithFlags(&side_streams[i], hipStreamNonBlocking));
             // pass 2: real plan
             dry = false;
             persist.base = persist_base; persist.reset();
-            for (int i = 0; i < 2; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
+            for (int i = 0; i < NS; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
             cur_sid = 0; aux_used = 0;
-            build_prepare_plan(); build_eps_plan();
+            build_prepare_plan();
+            persist_eps_begin = persist.off;           // everything above this is written by mkd_eps itself
+            build_eps_plan();
             ++plan_generation; drop_graph();
             // sampler buffers
             const size_t lat = (size_t)B * cfg.in_channels * h * w * sizeof(float);
@@ -1027,8 +1070,8 @@ struct mkd_ctx {
         io_x = x; io_t = t; io_out = out;
         run_main = stream; run_serial = !dual_stream;
         for (auto& op : plan_eps) {
-            const bool on_side = !run_serial && (op.sid == 1 || (op.sid == 2 && !capturing));
-            int rc = op.fn(on_side ? side_stream : stream);
+            const int sid = (op.sid == SID_HELPER && capturing) ? 0 : op.sid;
+            int rc = op.fn(stream_of(sid));
             if (rc) return rc;
         }
         return 0;
@@ -1044,30 +1087,18 @@ struct mkd_ctx {
         }
         return aux_used++;
     }
-    void op_edge(int from_sid, int to_sid) {          // `to` waits for everything enqueued so far on `from`
-        if (!dec_overlap) return;
+    // in_graph: also taken while capturing a hipGraph (the two decoder lanes: 2 edges per evaluation); the per-block helper
+    // edges are not (graph-side cross-stream edges cost more than they hide)
+    void op_edge(int from_sid, int to_sid, bool in_graph = false, bool always = false) {   // `to` waits for everything enqueued so far on `from`
+        if (!always && !dec_overlap && !dec_lanes) return;
         const int e = ev_new();
         mkd_ctx* self = this;
-        push(*cur_plan, [self, e, from_sid, to_sid](hipStream_t) {
-            if (self->run_serial || self->capturing || e < 0) return 0;      // graph nodes pay for every cross-stream edge: keep the decoder linear there
-            MKD_HIP_CHECK(hipEventRecord(self->aux_ev[e], from_sid ? self->side_stream : self->run_main));
-            MKD_HIP_CHECK(hipStreamWaitEvent(to_sid ? self->side_stream : self->run_main, self->aux_ev[e], 0));
+        push(*cur_plan, [self, e, from_sid, to_sid, in_graph](hipStream_t) {
+            if (self->run_serial || (self->capturing && !in_graph) || e < 0) return 0;      // graph nodes pay for every cross-stream edge: keep the decoder linear there
+            MKD_HIP_CHECK(hipEventRecord(self->aux_ev[e], self->stream_of(from_sid)));
+            MKD_HIP_CHECK(hipStreamWaitEvent(self->stream_of(to_sid), self->aux_ev[e], 0));
             return 0;
-        }, 0, 0.0, K_MISC, from_sid ? "edge side->main" : "edge main->side");
-    }
-
-    // side stream starts after everything already enqueued on the caller's stream (x, t, previous eval)
-    int fork_side() {
-        if (run_serial) return 0;
-        MKD_HIP_CHECK(hipEventRecord(ev_fork, run_main));
-        MKD_HIP_CHECK(hipStreamWaitEvent(side_stream, ev_fork, 0));
-        return 0;
-    }
-    int join_side() {
-        if (run_serial) return 0;
-        MKD_HIP_CHECK(hipEventRecord(ev_join, side_stream));
-        MKD_HIP_CHECK(hipStreamWaitEvent(run_main, ev_join, 0));
-        return 0;
+        }, 0, 0.0, K_MISC, "edge " + std::to_string(from_sid) + "->" + std::to_string(to_sid));
     }
 
     // one eps with a hipEvent pair around every plan op: per-kernel-class device time (bench roofline)
@@ -1088,13 +1119,13 @@ struct mkd_ctx {
         if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipStreamSynchronize");
         for (int k = 0; k < K_COUNT; ++k) { ms[k] = 0; flops[k] = 0; launches[k] = 0; }
         FILE* csv = (csv_path && !rc) ? fopen(csv_path, "w") : nullptr;
-        if (csv) fprintf(csv, "op,kind,label,ms,gflop\n");
+        if (csv) fprintf(csv, "op,kind,label,ms,gflop,stream\n");
         for (size_t i = 0; i < n && !rc; ++i) {
             float dt = 0.f;
             if (hipEventElapsedTime(&dt, ev[i], ev[i + 1]) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime"); break; }
             const Op& op = plan_eps[i];
             ms[op.kind] += dt; flops[op.kind] += op.flops; launches[op.kind] += op.launches;
-            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f\n", i, kind_name(op.kind).c_str(), op.label.c_str(), dt, op.flops / 1e9);
+            if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f,%d\n", i, kind_name(op.kind).c_str(), op.label.c_str(), dt, op.flops / 1e9, op.sid);
         }
         if (csv) fclose(csv);
         for (auto& e : ev) hipEventDestroy(e);
@@ -1547,9 +1578,23 @@ struct mkd_ctx {
         return 0;
     }
 
+    // race detector for the tests: fill every buffer that one mkd_eps produces (activations, temporaries, workspaces) with
+    // NaN patterns, so a kernel that runs ahead of its producer reads garbage instead of the previous call's (equal) values
+    int debug_poison() {
+        if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_debug_poison before mkd_prepare");
+        MKD_HIP_CHECK(hipDeviceSynchronize());
+        if (persist_cap > persist_eps_begin) MKD_HIP_CHECK(hipMemset(persist_base + persist_eps_begin, 0xFF, persist_cap - persist_eps_begin));
+        for (int i = 0; i < NS; ++i) {
+            if (temp_base[i]) MKD_HIP_CHECK(hipMemset(temp_base[i], 0xFF, temp_cap[i]));
+            if (splitk_ws[i]) MKD_HIP_CHECK(hipMemset(splitk_ws[i], 0xFF, splitk_ws_bytes[i]));
+            if (gn_ws[i]) MKD_HIP_CHECK(hipMemset(gn_ws[i], 0xFF, gn_ws_bytes[i]));
+        }
+        MKD_HIP_CHECK(hipDeviceSynchronize());
+        return 0;
+    }
+
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + (int64_t)(temp_cap[0] + temp_cap[1]) + (int64_t)(splitk_ws_bytes[0] + splitk_ws_bytes[1]) +
-               (int64_t)(gn_ws_bytes[0] + gn_ws_bytes[1]);
+        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + [&] { int64_t t = 0; for (int i = 0; i < NS; ++i) t += (int64_t)(temp_cap[i] + splitk_ws_bytes[i] + gn_ws_bytes[i]); return t; }();
     }
 
     ~mkd_ctx() {
@@ -1562,8 +1607,12 @@ struct mkd_ctx {
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
         if (h_state) hipHostFree(h_state);
         if (s_state) hipFree(s_state);
-        if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
-        for (void* p : {(void*)persist_base, (void*)temp_base[0], (void*)temp_base[1], (void*)splitk_ws[0], (void*)splitk_ws[1], (void*)gn_ws[0], (void*)gn_ws[1], (void*)s_xa, (void*)s_xb,
+        for (int i = 1; i < NS; ++i)
+            if (side_streams[i]) { hipStreamSynchronize(side_streams[i]); hipStreamDestroy(side_streams[i]); }
+        for (int i = 0; i < NS; ++i)
+            for (void* p : {(void*)temp_base[i], (void*)splitk_ws[i], (void*)gn_ws[i]})
+                if (p) hipFree(p);
+        for (void* p : {(void*)persist_base, (void*)s_xa, (void*)s_xb,
                         (void*)s_xin, (void*)s_eps, (void*)s_t})
             if (p) hipFree(p);
     }
@@ -1663,6 +1712,7 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
                        (hipStream_t)stream);
 }
 int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
+int mkd_debug_poison(mkd_ctx* ctx) { return ctx ? ctx->debug_poison() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
 int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk) {
     gemm_set_override(M, N, K, conv3x3, stride, up, cfg, splitk);
     return 0;

@@ -290,6 +290,11 @@ class MkdEngine:
                                                 C.c_void_p(_stream())), 'mkd_clip_encode')
         return out
 
+    def debug_poison(self) -> None:
+        """Tests only: NaN-fill everything one eps evaluation produces (see mkd_debug_poison)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mkd_debug_poison(self._ctx), 'mkd_debug_poison')
+
     def decode_flops(self) -> float:
         return float(self.lib.mkd_decode_flops(self._ctx))
 

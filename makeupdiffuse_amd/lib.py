@@ -74,6 +74,7 @@ SIGNATURES = {
     'mkd_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mkd_gemm_force_tile': (_I, [_I]),
+    'mkd_debug_poison': (_I, [_P]),
     'mkd_gemm_set_override': (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'mkd_gemm_cfg_supported': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     'mkd_fold_layernorm': (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P]),

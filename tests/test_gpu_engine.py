@@ -215,3 +215,36 @@ def test_full_size_eps_vs_oracle():
     # hint block 1.87 GMAC + cross-attention K/V projections 2.16 GMAC -> 117.39 GMAC executed per eval
     assert abs(eng.eps_flops() / 2e9 - 117.39) < 0.05
     eng.close()
+
+
+@pytest.mark.parametrize('dec_lanes,enc_lanes,overlap', [(0, 0, 1), (0, 0, 0), (2, 0, 1), (4, 0, 1), (2, 1, 1), (4, 1, 1)])
+def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overlap, monkeypatch):
+    """Every multi-stream configuration (decoder helpers on the side stream, half-/quarter-batch decoder lanes, half-batch
+    encoder lanes): NaN-poison all buffers an evaluation produces, evaluate, and require the golden result, bit-identical
+    across repetitions - a kernel that runs ahead of its producer would read NaN instead of the previous call's values."""
+    monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes)); monkeypatch.setenv('MKD_ENC_LANES', str(enc_lanes))
+    monkeypatch.setenv('MKD_DEC_OVERLAP', str(overlap))
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.load_state_dict(sd)
+    G = {k: torch.from_numpy(g[k]) for k in g.files if k != 'seed_weights'}
+    rep = lambda t: torch.cat([t, t, t[:1]])                      # batch 5: ragged lanes (1+1+1+2 or 2+3)
+    for hint, want in ((rep(G['hint']), rep(G['eps'])), (None, rep(G['eps_noctl']))):
+        eng.prepare(hint, rep(G['ctx']), latent_hw=(8, 8))
+        first = None
+        for i in range(4):
+            eng.debug_poison()
+            out = eng.eps(rep(G['x']), rep(G['t']))
+            check_eps(out, want, what=f'lanes dec={dec_lanes} enc={enc_lanes} overlap={overlap} rep {i}')
+            first = out if first is None else first
+            assert torch.equal(out, first)
+        # the captured-graph loop takes the same plan
+        sch_t = [801, 601, 401, 201]
+        eng.debug_poison()
+        a = eng.sample(rep(G['x']), sch_t, [0.1, 0.3, 0.6, 0.9], [0.3, 0.6, 0.9, 0.99], [0.95, 0.84, 0.63, 0.31], use_graph=False)
+        eng.debug_poison()
+        b = eng.sample(rep(G['x']), sch_t, [0.1, 0.3, 0.6, 0.9], [0.3, 0.6, 0.9, 0.99], [0.95, 0.84, 0.63, 0.31], use_graph=True)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    eng.close()
