@@ -61,6 +61,24 @@ __device__ __forceinline__ f32x4 epilogue_value(const Epilogue& e, int m, int n,
     return v;
 }
 
+// same with bias / residual fragments that were loaded before the K loop
+__device__ __forceinline__ f32x4 epilogue_value_pre(const Epilogue& e, int m, int n, f32x4 v, f32x4 bias, U16x4 res) {
+    v += bias;
+    if (e.rowbias) v += *(const f32x4*)(e.rowbias + (size_t)(m / e.rpb) * e.ldrb + n);
+    v *= e.scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(res.v[j]);
+    if (e.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+    }
+    if (e.act == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = quick_gelu_f(v[j]);
+    }
+    return v;
+}
+
 // stores v (already through epilogue_value); returns the values as the consumer will read them (bf16-rounded)
 __device__ __forceinline__ f32x4 epilogue_write(const Epilogue& e, int m, int n, f32x4 v) {
     if (e.act == 2) {

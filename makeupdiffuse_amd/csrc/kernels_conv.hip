@@ -155,6 +155,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     // ---- K loop over (chunk, tap) ------------------------------------------------------------------------------
     const int nch = c_end - c_begin;
     const int nsteps = nch * 9;
+    // bias / residual fragments first: older than every tile load (in-order vmcnt: the counted waits are unaffected), so their
+    // latency hides under the K loop instead of being paid after it
+    const bool pre = splitk == 1;
+    f32x4 pbias[NI];
+    U16x4 pres[NI][MI];
+    if (pre) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+            pbias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (epi.bias && n < N) pbias[ni] = *(const f32x4*)(epi.bias + n);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pres[ni][mi].v[j] = 0;
+                if (epi.R && n < N && mrow[mi] >= 0) pres[ni][mi] = *(const U16x4*)(epi.R + (size_t)mrow[mi] * epi.ldr + n);
+            }
+        }
+    }
     if (nsteps > 0) {
         issue_patch(0, c_begin);
         {
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
             const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
             if (n >= N) continue;
             if (splitk > 1) *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
-            else epilogue_store(epi, m, n, acc[ni][mi]);
+            else epilogue_write(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
         }
     }
 }

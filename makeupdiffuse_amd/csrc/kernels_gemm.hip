@@ -174,6 +174,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     // Every wave issues exactly LPT loads per tile, in order, so "tile i landed" == "at most LPT * (tiles
     // issued after i) of my loads are still outstanding": a counted s_waitcnt, never a full drain.
     const int ntile = kt_end - kt_begin;
+    // Epilogue operands (bias, residual) are fetched FIRST: older than every tile load, they retire before tile 0 is waited on
+    // (vmcnt is in-order, so the counted waits below are unaffected) and their latency hides under the K loop instead of being
+    // paid after it - these layers are latency-bound and K is often 5 steps.
+    const bool pre = splitk == 1 && !LN;
+    f32x4 pbias[NI];
+    U16x4 pres[NI][MI];
+    if (pre) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * (lane >> 4);
+            pbias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (epi.bias && n < N) pbias[ni] = *(const f32x4*)(epi.bias + n);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + wm * (TM / WM) + mi * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pres[ni][mi].v[j] = 0;
+                if (epi.R && n < N && m < M) pres[ni][mi] = *(const U16x4*)(epi.R + (size_t)m * epi.ldr + n);
+            }
+        }
+    }
     if (ntile > 0) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
                     *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
                 } else {
                     const f32x4 v0 = LN ? ln_correct(ln_s, n, acc[ni][mi], mu, rstd) : acc[ni][mi];
-                    const f32x4 r = epilogue_write(epi, m, n, epilogue_value(epi, m, n, v0));
+                    const f32x4 r = epilogue_write(epi, m, n, pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0));
                     ps += (r[0] + r[1]) + (r[2] + r[3]);
                     pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
                 }
