@@ -292,6 +292,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
     const bool ok = n < p.N && m < p.M;
     float ps = 0.f, pq = 0.f;
     if (ok) {
+        const Epilogue e = make_epilogue(p);
+        // bias / residual first, so that their latency overlaps the slab loads instead of following them
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        U16x4 r4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r4.v[j] = 0;
+        if (e.bias) b4 = *(const f32x4*)(e.bias + n);
+        if (e.R) r4 = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
         const size_t slab = (size_t)p.M * p.N;
         const float* src = p.ws + (size_t)m * p.N + n;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -304,8 +312,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
             v += (a + b) + (c + d);
         }
         for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
-        const Epilogue e = make_epilogue(p);
-        const f32x4 r = epilogue_write(e, m, n, epilogue_value(e, m, n, v));
+        const f32x4 r = epilogue_write(e, m, n, epilogue_value_pre(e, m, n, v, b4, r4));
         ps = (r[0] + r[1]) + (r[2] + r[3]);
         pq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
     }

@@ -178,6 +178,14 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
             }
         }
     }
+    // gamma / beta of this thread's 8 channels: fetched now, next to the slab loads, not after the statistics barriers
+    float pg[8], pb[8];
+    if (active) {
+        const f32x4 g0 = *(const f32x4*)(gamma + c0 + v * 8), g1 = *(const f32x4*)(gamma + c0 + v * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c0 + v * 8), b1 = *(const f32x4*)(beta + c0 + v * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[j] = g0[j]; pg[4 + j] = g1[j]; pb[j] = b0[j]; pb[4 + j] = b1[j]; }
+    }
     float* ssum = s_red;                      // [NT][8]
     float* ssq = s_red + NT * 8;              // [NT][8]
     float* csum = s_red + 2 * NT * 8;         // [nch] per-channel totals
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
     for (int j = 0; j < 8; ++j) {
         const int cl = v * 8 + j;
         const int g = cl / cg;
-        const float a = gamma[c0 + cl] * gstat[g * 2 + 1];
+        const float a = pg[j] * gstat[g * 2 + 1];
         sa[j] = a;
-        sb[j] = beta[c0 + cl] - gstat[g * 2] * a;
+        sb[j] = pb[j] - gstat[g * 2] * a;
     }
     bf16_t* yout = y + (size_t)b * hw * ld_out + c0 + v * 8;
     auto apply_store = [&](const U16x8& d, int r) {
@@ -261,7 +269,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     if (row >= rows) return;
     const int V = d >> 3;
     float f[NV][8];
+    f32x4 pg[NV][2], pb[NV][2];               // gamma / beta: issued together with the row, consumed after the statistics
     float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+            pg[i][0] = *(const f32x4*)(gamma + v * 8); pg[i][1] = *(const f32x4*)(gamma + v * 8 + 4);
+            pb[i][0] = *(const f32x4*)(beta + v * 8); pb[i][1] = *(const f32x4*)(beta + v * 8 + 4);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = lane + 64 * i;
@@ -292,8 +309,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             U16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c = v * 8 + j;
-                o.v[j] = f32_to_bf16((f[i][j] - mean) * rstd * gamma[c] + beta[c]);
+                o.v[j] = f32_to_bf16((f[i][j] - mean) * rstd * pg[i][j >> 2][j & 3] + pb[i][j >> 2][j & 3]);
             }
             *(U16x8*)(y + (size_t)row * d + v * 8) = o;
         }
