@@ -191,6 +191,38 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
     float* csum = s_red + 2 * NT * 8;         // [nch] per-channel totals
     float* csq = csum + nch;
     float* gstat = csq + nch;                 // [gpb][2] mean, rstd
+    if (cg >= 8) {
+        // Group statistics straight from the registers (block-uniform branch): a thread's 8 channels touch at most two groups;
+        // per group a masked butterfly over the wave, then a fixed-order sum over the waves - two barriers, deterministic.
+        const int gA = (v * 8) / cg;
+        const int split = min(8, (gA + 1) * cg - v * 8);          // channels [0, split) belong to gA, the rest to gA + 1
+        float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < split) { a0 += sum[j]; q0 += sq[j]; } else { a1 += sum[j]; q1 += sq[j]; }
+            }
+        }
+        const int nw = NT >> 6, wv = tid >> 6;
+        for (int g = 0; g < gpb; ++g) {
+            float sg = (gA == g ? a0 : 0.f) + (gA + 1 == g ? a1 : 0.f);
+            float qg = (gA == g ? q0 : 0.f) + (gA + 1 == g ? q1 : 0.f);
+            sg = wave_sum(sg); qg = wave_sum(qg);
+            if ((tid & 63) == 0) { s_red[(wv * gpb + g) * 2] = sg; s_red[(wv * gpb + g) * 2 + 1] = qg; }
+        }
+        __syncthreads();
+        if (tid < gpb) {
+            float a = 0.f, q = 0.f;
+            for (int k = 0; k < nw; ++k) { a += s_red[(k * gpb + tid) * 2]; q += s_red[(k * gpb + tid) * 2 + 1]; }
+            const float n = (float)hw * (float)cg;
+            const float mean = a / n;
+            float var = q / n - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            gstat[tid * 2] = mean;
+            gstat[tid * 2 + 1] = rsqrtf(var + eps);
+        }
+        __syncthreads();
+    } else {
     if (active) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ssum[tid * 8 + j] = sum[j]; ssq[tid * 8 + j] = sq[j]; }
@@ -219,6 +251,7 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
         gstat[tid * 2 + 1] = rsqrtf(var + eps);
     }
     __syncthreads();
+    }
     if (!active) return;
     float sa[8], sb[8];
 #pragma unroll

@@ -40,9 +40,25 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }      // CLIP: x * sigmoid(1.702 x)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Activation math on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): an IEEE division costs ~10 VALU
+// ops and libm erff ~40, and the element-wise kernels here are VALU-bound on the few CUs a GroupNorm can occupy.
+__device__ __forceinline__ float sigmoid_scaled_f(float x, float k) {            // 1 / (1 + exp(-k x))
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.4426950408889634f * k)));
+}
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_scaled_f(x, 1.0f); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_scaled_f(x, 1.702f); }      // CLIP: x * sigmoid(1.702 x)
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step): GELU(x) = x/2 * (1 + erf(x / sqrt 2))
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 struct __attribute__((aligned(16))) U16x8 { uint16_t v[8]; };
 struct __attribute__((aligned(8)))  U16x4 { uint16_t v[4]; };
