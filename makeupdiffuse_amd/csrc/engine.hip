@@ -127,14 +127,17 @@ struct mkd_ctx {
     int n_ctrl() const { return (int)encoder_spec().size() + 1; }
     static constexpr int NS = 4;              // streams / temp arenas: 0 = caller's stream, 1..3 = side streams
     static constexpr int SID_HELPER = 8;      // decoder helper GEMMs: side stream 1 unless capturing (arena 1)
-    Arena persist, temp_arena[NS];
+    static constexpr int SID_AUX = 4;         // first-stage decoder / text encoder plans: private workspaces, so that they may run
+                                              // on another stream concurrently with an evaluation (pipelined decode)
+    static constexpr int NA = NS + 1;         // workspace sets: one per stream + SID_AUX
+    Arena persist, temp_arena[NA];
     int cur_sid = 0;
     static int arena_of(int sid) { return sid == SID_HELPER ? 1 : sid; }
     Arena& TA() { return temp_arena[arena_of(cur_sid)]; }
-    char* persist_base = nullptr; char* temp_base[NS] = {};
-    size_t persist_cap = 0, temp_cap[NS] = {};
-    float* splitk_ws[NS] = {}; size_t splitk_ws_bytes[NS] = {}, splitk_need = 0;
-    float* gn_ws[NS] = {}; size_t gn_ws_bytes[NS] = {}, gn_need = 0;
+    char* persist_base = nullptr; char* temp_base[NA] = {};
+    size_t persist_cap = 0, temp_cap[NA] = {};
+    float* splitk_ws[NA] = {}; size_t splitk_ws_bytes[NA] = {}, splitk_need = 0;
+    float* gn_ws[NA] = {}; size_t gn_ws_bytes[NA] = {}, gn_need = 0;
     hipStream_t side_streams[NS] = {};        // [0] unused (the caller's stream)
     hipStream_t stream_of(int sid) const { return (sid == 0 || run_serial) ? run_main : side_streams[sid == SID_HELPER ? 1 : sid]; }
     hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
@@ -1353,7 +1356,7 @@ struct mkd_ctx {
     }
 
     void build_vae_plan(int Bn, int hh, int ww) {
-        cur_plan = &plan_vae; cur_sid = 0; counting_eps = false;
+        cur_plan = &plan_vae; cur_sid = SID_AUX; counting_eps = false;
         mkd_ctx* self = this;
         const std::string P = vae_prefix(), D = P + "decoder.";
         const int zc = vcfg.z_channels;
@@ -1421,16 +1424,18 @@ struct mkd_ctx {
         if (Bn != vae_B || hh != vae_h || ww != vae_w) {
             // same two-pass scheme as mkd_prepare: dry run sizes the arena, second pass binds pointers
             const size_t keep_sk = splitk_need, keep_gn = gn_need;
+            splitk_need = 0; gn_need = 0;
             dry = true; varena.base = nullptr; varena.reset(); plan_vae.clear(); flops_vae = 0;
             build_vae_plan(Bn, hh, ww);
             int rc = ensure((void**)&varena_base, &varena_cap, varena.high + 256); if (rc) return rc;
-            rc = ensure((void**)&splitk_ws[0], &splitk_ws_bytes[0], std::max(splitk_need, keep_sk)); if (rc) return rc;
-            rc = ensure((void**)&gn_ws[0], &gn_ws_bytes[0], std::max(gn_need, keep_gn)); if (rc) return rc;
+            rc = ensure((void**)&splitk_ws[SID_AUX], &splitk_ws_bytes[SID_AUX], std::max(splitk_need, splitk_ws_bytes[SID_AUX])); if (rc) return rc;
+            rc = ensure((void**)&gn_ws[SID_AUX], &gn_ws_bytes[SID_AUX], std::max(gn_need, gn_ws_bytes[SID_AUX])); if (rc) return rc;
+            splitk_need = keep_sk; gn_need = keep_gn;          // (the evaluation plans keep their own maxima)
             dry = false; varena.base = varena_base; varena.reset(); plan_vae.clear();
             build_vae_plan(Bn, hh, ww);
+            splitk_need = keep_sk; gn_need = keep_gn;
             for (auto& op : plan_vae) flops_vae += op.flops;
             vae_B = Bn; vae_h = hh; vae_w = ww;
-            drop_graph();            // workspaces may have moved
         }
         io_z = z; io_img = images; io_inv_scale = 1.0f / scale_factor;
         for (auto& op : plan_vae) { int rc = op.fn(stream); if (rc) return rc; }
@@ -1514,7 +1519,7 @@ struct mkd_ctx {
     }
 
     void build_clip_plan(int Bn, int T) {
-        cur_plan = &plan_clip; cur_sid = 0; counting_eps = false;
+        cur_plan = &plan_clip; cur_sid = SID_AUX; counting_eps = false;
         mkd_ctx* self = this;
         const std::string P = clip_prefix();
         const int W = ccfg.width, I = ccfg.intermediate, heads = ccfg.heads, dh = W / heads, rows = Bn * T;
@@ -1564,14 +1569,15 @@ struct mkd_ctx {
         if (T > ccfg.max_positions) return mkd_fail(MKD_ERR_ARG, "mkd_clip_encode: more tokens than position embeddings");
         if (Bn != clip_B || T != clip_T) {
             const size_t keep_sk = splitk_need;
+            splitk_need = 0;
             dry = true; carena.base = nullptr; carena.reset(); plan_clip.clear();
             build_clip_plan(Bn, T);
             int rc = ensure((void**)&carena_base, &carena_cap, carena.high + 256); if (rc) return rc;
-            rc = ensure((void**)&splitk_ws[0], &splitk_ws_bytes[0], std::max(splitk_need, keep_sk)); if (rc) return rc;
+            rc = ensure((void**)&splitk_ws[SID_AUX], &splitk_ws_bytes[SID_AUX], std::max(splitk_need, splitk_ws_bytes[SID_AUX])); if (rc) return rc;
             dry = false; carena.base = carena_base; carena.reset(); plan_clip.clear();
             build_clip_plan(Bn, T);
+            splitk_need = keep_sk;
             clip_B = Bn; clip_T = T;
-            drop_graph();            // workspaces may have moved
         }
         io_tokens = tokens; io_ctx_out = out;
         for (auto& op : plan_clip) { int rc = op.fn(stream); if (rc) return rc; }
@@ -1594,7 +1600,7 @@ struct mkd_ctx {
     }
 
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + [&] { int64_t t = 0; for (int i = 0; i < NS; ++i) t += (int64_t)(temp_cap[i] + splitk_ws_bytes[i] + gn_ws_bytes[i]); return t; }();
+        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + [&] { int64_t t = 0; for (int i = 0; i < NA; ++i) t += (int64_t)(temp_cap[i] + splitk_ws_bytes[i] + gn_ws_bytes[i]); return t; }();
     }
 
     ~mkd_ctx() {
@@ -1609,7 +1615,7 @@ struct mkd_ctx {
         if (s_state) hipFree(s_state);
         for (int i = 1; i < NS; ++i)
             if (side_streams[i]) { hipStreamSynchronize(side_streams[i]); hipStreamDestroy(side_streams[i]); }
-        for (int i = 0; i < NS; ++i)
+        for (int i = 0; i < NA; ++i)
             for (void* p : {(void*)temp_base[i], (void*)splitk_ws[i], (void*)gn_ws[i]})
                 if (p) hipFree(p);
         for (void* p : {(void*)persist_base, (void*)s_xa, (void*)s_xb,
