@@ -16,9 +16,10 @@
 namespace {
 
 constexpr int KT = 64;            // keys per tile
-// MKD_ATTN_TAIL=1 sends the last 8 / 16 channels of dh = 40 / 80 through one 16-deep MFMA (40 padded to 48, not 64): +9 % at
-// 4096 tokens, but the 8-wave build then returns wrong scores (a 16x16x32 result feeding a 16x16x16 SrcC with a different
-// vDst, VGPR form; the 4-wave build keeps the accumulators in AGPRs and is right) -> OFF until that is understood.
+// MKD_ATTN_TAIL=1 sends the last 8 / 16 channels of dh = 40 / 80 through one 16-deep MFMA (40 padded to 48, not 64).  In the
+// 8-wave build (accumulators in VGPRs) a 16x16x16 result feeding a 16x16x32 SrcC, or the reverse, was read too early
+// (sporadically wrong scores; the 4-wave build keeps them in AGPRs and is right); with 32 explicit wait states it is correct
+// but only 3 % faster at 4096 tokens and slower at 1024 -> OFF.
 #ifndef MKD_ATTN_TAIL
 #define MKD_ATTN_TAIL 0
 #endif
@@ -149,14 +150,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
         for (int mf = 0; mf < 4; ++mf) {
             st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             const char* krow = ks + (16 * mf + qc) * C::KROW;
+            if (C::TAIL) {                   // the 16-deep step first: the 32-deep steps then accumulate on its result
+                const bf16x4v kt = *(const bf16x4v*)(krow + (32 * C::KS + 4 * g) * 2);
+                st[mf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kt), __builtin_bit_cast(s16x4, qt), st[mf], 0, 0, 0);
+                // A 16x16x16 result feeding a 16x16x32 MFMA's SrcC (VGPR form, different vDst) was observed to be read too early
+                // in the 8-wave build (sporadically wrong scores): keep 32 wait states between the two, tied to the register.
+                if (C::KS) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(st[mf]));
+            }
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) {
                 const bf16x8 kf = *(const bf16x8*)(krow + (32 * s + 8 * g) * 2);
                 st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[mf], 0, 0, 0);
-            }
-            if (C::TAIL) {
-                const bf16x4v kt = *(const bf16x4v*)(krow + (32 * C::KS + 4 * g) * 2);
-                st[mf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kt), __builtin_bit_cast(s16x4, qt), st[mf], 0, 0, 0);
             }
         }
         // lane holds RAW scores of query qc for keys key0 + 16*mf + 4*g + r.  The softmax runs in the log2 domain with the
