@@ -81,8 +81,8 @@ struct Op {
     int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
 };
 
-// kinds: [0, 17) conv GEMM by tile config, [17, 34) linear GEMM by tile config, then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 17, K_GROUPNORM = 34, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+// kinds: [0, 20) conv GEMM by tile config, [20, 40) linear GEMM by tile config, then the rest
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 20, K_GROUPNORM = 40, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};

@@ -337,12 +337,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 //   14: 64x160 3 stages (86 KiB), 15: 128x160 3 stages (110 KiB), 16: 64x160 2 stages (57 KiB, 2 blocks/CU): every channel
 //       count of the nets is a multiple of 320, so 160-wide column tiles never run a partly empty tile (N = 320 -> 2 x 160
 //       instead of 3 x 128 with 17 % of the MFMA work wasted)
-constexpr int N_TILE_CFG = 17;
-static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64};
-static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160};
+//   17: 32x64, 18: 64x32, 19: 32x32 (4 stages): one CU streams at most ~55 GB/s (tools/micro/stream_rate.hip), so a GEMM with
+//       fewer blocks than CUs finishes sooner when each block pulls FEWER operand bytes ((TM + TN) * K * 2), not more
+constexpr int N_TILE_CFG = 20;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
-                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2"};
+                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32"};
 static bool is_patch_cfg(int c) { return c >= 6 && c <= 11; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -370,7 +372,7 @@ void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cf
     ++g_plan_epoch;
     if (M <= 0) { g_override.clear(); return; }
     const ShapeKey k{M, N, K, conv, stride, up};
-    if (cfg < 0 || cfg >= 17) { g_override.erase(k); return; }
+    if (cfg < 0 || cfg >= N_TILE_CFG) { g_override.erase(k); return; }
     TunedEntry e{}; e.M = M; e.N = N; e.K = K; e.conv = conv; e.stride = stride; e.up = up; e.cfg = cfg; e.splitk = splitk < 1 ? 1 : splitk;
     g_override[k] = e;
 }
@@ -526,6 +528,9 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         case 14: rc = launch_tile<64, 160, 2, 2, 3>(a, g.splitk, stream); break;
         case 15: rc = launch_tile<128, 160, 2, 2, 3>(a, g.splitk, stream); break;
         case 16: rc = launch_tile<64, 160, 2, 2, 2>(a, g.splitk, stream); break;
+        case 17: rc = launch_tile<32, 64, 2, 2, 4>(a, g.splitk, stream); break;
+        case 18: rc = launch_tile<64, 32, 2, 2, 4>(a, g.splitk, stream); break;
+        case 19: rc = launch_tile<32, 32, 2, 2, 4>(a, g.splitk, stream); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
     }
     if (rc) return rc;
