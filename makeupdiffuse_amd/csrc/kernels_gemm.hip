@@ -446,8 +446,13 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
 
 int gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).splitk; }
 int gemm_max_splitk() { return 32; }
+// producers of fused-LayerNorm row statistics keep column tiles >= 64 wide (one statistics slot per column tile, <= 20 slots)
+static GemmPlan stat_producer_plan(GemmPlan g) {
+    if (kTileN[g.cfg] < 64) g.cfg = 5;
+    return g;
+}
 int gemm_stat_slots(int M, int N, int K) {
-    const GemmPlan g = gemm_plan(M, N, K, 0);
+    const GemmPlan g = stat_producer_plan(gemm_plan(M, N, K, 0));
     if (g.splitk > 1) return (N + 255) / 256;
     return (N + kTileN[g.cfg] - 1) / kTileN[g.cfg];            // one slot per column tile
 }
@@ -505,6 +510,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         g.per = (a.K + BK - 1) / BK;
     }
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
+    if (a.stat_out) g = stat_producer_plan(g);
     if (is_patch_cfg(g.cfg)) {
         if (conv_patch_supported(a, g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
         if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
