@@ -144,6 +144,7 @@ struct mkd_ctx {
     // measured at batch 8, 256x256 (ms per evaluation): no lanes 6.78, 2 decoder lanes 6.58, 4 decoder lanes 6.89, encoder lanes
     // on top +0.25: the encoder phase already runs two nets side by side, a third and fourth stream only add contention
     int dec_lanes = getenv("MKD_DEC_LANES") ? atoi(getenv("MKD_DEC_LANES")) : 2;          // 0 / 2 / 4 half- or quarter-batch decoder lanes
+    int dec_lanes_from = getenv("MKD_DEC_LANES_FROM") ? atoi(getenv("MKD_DEC_LANES_FROM")) : 0;   // deepest blocks as one full-batch chain first
     bool enc_lanes = getenv("MKD_ENC_LANES") ? atoi(getenv("MKD_ENC_LANES")) != 0 : false;
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
     bool capturing = false;
@@ -895,7 +896,8 @@ struct mkd_ctx {
         // One decoder pass over samples [b0, b0 + nb).  helpers_on_side: the zero-conv "combine" GEMMs (skip + scale *
         // zero_conv(cn_feat), written straight into the concat buffer's skip half) and the ResBlocks' 1x1 skip GEMMs only depend
         // on the encoders / the block input, so they run on the side stream under the main GN -> conv -> GN chain.
-        auto emit_decoder = [&](int b0, int nb, bool helpers_on_side) {
+        // blocks [i0, i1); first_combined: block i0's concat input was already completed by the previous phase
+        auto emit_decoder = [&](int b0, int nb, bool helpers_on_side, size_t i0, size_t i1, bool first_combined) {
             const int main_sid = cur_sid;
             const int help_sid = helpers_on_side ? SID_HELPER : main_sid;
             auto combine = [&](size_t i) {          // emits on the CURRENT sid
@@ -923,9 +925,9 @@ struct mkd_ctx {
                 }
             };
             if (helpers_on_side) op_edge(0, 1);     // side: both encoders are complete (main already joined the ControlNet)
-            cur_sid = help_sid; combine(0); cur_sid = main_sid;
+            if (!first_combined) { cur_sid = help_sid; combine(i0); cur_sid = main_sid; }
             Tensor cat;
-            for (size_t i = 0; i < dec.size(); ++i) {
+            for (size_t i = i0; i < i1; ++i) {
                 const BlockSpec& bs = dec[i];
                 cat = slice(cats[i], b0, nb);
                 if (helpers_on_side) op_edge(1, 0);  // main: this block's concat input is complete
@@ -962,7 +964,7 @@ struct mkd_ctx {
                 TA().release(mk);
             }
             // out: GN32 + SiLU + conv3x3 C -> out_channels (fp32 NCHW)
-            {
+            if (i1 == dec.size()) {
                 const Tensor fin = slice(final_t, b0, nb);
                 const size_t mk = TA().mark();
                 Tensor g = talloc(TA(), fin.B, fin.H, fin.W, fin.C);
@@ -978,13 +980,20 @@ struct mkd_ctx {
         };
         const int DL = (dec_lanes >= 4 && B >= 4) ? 4 : ((dec_lanes >= 2 && B >= 2) ? 2 : 1);
         if (DL > 1) {
+            // Optional first phase: the deepest blocks [0, lanes_from) as ONE full-batch chain (they stream weights; a second
+            // lane would stream them again), helpers on the side stream; then batch-slice lanes.
+            const size_t from = (size_t)std::min<int>(std::max(dec_lanes_from, 0), (int)dec.size() - 1);
+            if (from > 0) {
+                emit_decoder(0, B, dec_overlap, 0, from, false);
+                if (dec_overlap) op_edge(1, 0);     // the helper's combine of block `from` (lane 1 shares the helper's stream)
+            }
             // Batch-slice lanes: every op is per-sample, so lane l decodes its share of the samples on stream l, host enqueue
             // interleaved.  Also inside a hipGraph capture (one fork / join edge per extra lane).
             std::vector<Op> lane_ops[NS];
             for (int l = 0; l < DL; ++l) {
                 const int b0 = (int)((int64_t)B * l / DL), b1 = (int)((int64_t)B * (l + 1) / DL);
                 cur_plan = &lane_ops[l]; cur_sid = l;
-                emit_decoder(b0, b1 - b0, false);
+                emit_decoder(b0, b1 - b0, false, from, dec.size(), from > 0);
             }
             cur_plan = &plan_eps; cur_sid = 0;
             for (int l = 1; l < DL; ++l) op_edge(0, l, true, true);     // lanes start after the encoders (all joined on main)
@@ -996,7 +1005,7 @@ struct mkd_ctx {
             }
             for (int l = 1; l < DL; ++l) op_edge(l, 0, true, true);     // the evaluation ends when every lane has
         } else {
-            emit_decoder(0, B, dec_overlap);
+            emit_decoder(0, B, dec_overlap, 0, dec.size(), false);
         }
         counting_eps = false;
     }
