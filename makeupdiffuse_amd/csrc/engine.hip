@@ -110,6 +110,8 @@ struct mkd_ctx {
     // LayerNorm folded into its consumer GEMMs: W' = W*gamma (bf16), s = rowsum(W'), b' = b + W.beta
     std::map<std::string, bf16_t*> q2_w; std::map<std::string, float*> qkv_s, qkv_b, q2_s, q2_b, ffg_s;
     std::map<std::string, bf16_t*> qkv_plain, ffp_w; std::map<std::string, float*> ffp_b;     // the unfolded counterparts
+    std::map<std::string, bf16_t*> ffm_w; std::map<std::string, float*> ffm_b;                // [P.W2 | P], P.b2 + bp: FF2 + proj_out as one GEMM
+    bool merge_ffout = getenv("MKD_MERGE_FFOUT") ? atoi(getenv("MKD_MERGE_FFOUT")) != 0 : true;
     std::map<std::string, float*> f32_keep;      // fp32 copies of the weights that get folded (kept for re-finalize)
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
@@ -373,7 +375,8 @@ struct mkd_ctx {
         const std::string nm(name);
         auto ends = [&](const char* suf) { const size_t L = strlen(suf); return nm.size() >= L && nm.compare(nm.size() - L, L, suf) == 0; };
         if (!rc && e == hipSuccess && (ends(".attn1.to_q.weight") || ends(".attn1.to_k.weight") || ends(".attn1.to_v.weight") ||
-                                      ends(".attn2.to_q.weight") || ends(".ff.net.0.proj.weight"))) {
+                                      ends(".attn2.to_q.weight") || ends(".ff.net.0.proj.weight") || ends(".ff.net.2.weight") ||
+                                      ends(".proj_out.weight"))) {
             auto it2 = f32_keep.find(nm);
             if (it2 != f32_keep.end()) hipFree(it2->second); else weight_bytes += n * (int64_t)sizeof(float);
             f32_keep[nm] = stage;
@@ -415,7 +418,7 @@ struct mkd_ctx {
             zero_page = (bf16_t*)z;
         }
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
-        q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear();
+        q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear(); ffm_w.clear(); ffm_b.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
@@ -440,6 +443,17 @@ struct mkd_ctx {
                     MKD_HIP_CHECK(hipMemcpy2D(b2, 8, pb.dev, 4, 4, inner, hipMemcpyDeviceToDevice));
                     MKD_HIP_CHECK(hipMemcpy2D((char*)b2 + 4, 8, (const char*)pb.dev + inner * 4, 4, 4, inner, hipMemcpyDeviceToDevice));
                     ffp_w[p] = (bf16_t*)w2; ffp_b[p] = (float*)b2;
+                    // FF2 and proj_out are both linear with nothing in between: one GEMM over [gg | h2] (K = 5d)
+                    auto kp = f32_keep.find(p + ".proj_out.weight"); auto kw = f32_keep.find(t + ".ff.net.2.weight");
+                    if (merge_ffout && kp != f32_keep.end() && kw != f32_keep.end()) {
+                        const int dd = (int)params.at(p + ".norm.weight").numel();
+                        void* wm = nullptr; void* bm = nullptr;
+                        rc = dev_alloc(&wm, (size_t)dd * 5 * dd * sizeof(bf16_t)); if (rc) return rc;
+                        rc = dev_alloc(&bm, (size_t)dd * sizeof(float)); if (rc) return rc;
+                        rc = launch_merge_ff_out(kp->second, kw->second, wf(t + ".ff.net.2.bias"), wf(p + ".proj_out.bias"), (bf16_t*)wm, (float*)bm, dd, 0);
+                        if (rc) return rc;
+                        ffm_w[p] = (bf16_t*)wm; ffm_b[p] = (float*)bm;
+                    }
                 }
                 const int d = (int)params.at(p + ".norm.weight").numel();
                 auto keep = [&](const std::string& n) -> const float* {
@@ -579,8 +593,8 @@ struct mkd_ctx {
             return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[arena_of(sid)], st);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
     }
-    void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d) {
-        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st); }, 1, 0.0, K_LAYERNORM,
+    void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d, int ldx = 0) {
+        push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st, ldx); }, 1, 0.0, K_LAYERNORM,
              "rows=" + std::to_string(rows) + " d=" + std::to_string(d));
     }
     void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
@@ -653,12 +667,14 @@ struct mkd_ctx {
         const bool fl = fuse_ln && slots <= 20;
         auto sbuf = [&]() { return fl ? (float*)TA().alloc((size_t)slots * M * 2 * sizeof(float)) : nullptr; };
         float* st0 = sbuf(); float* st1 = sbuf(); float* st2 = sbuf();
-        auto ln_input = [&](const bf16_t* hsrc, const std::string& norm) -> const bf16_t* {      // plain path: LN kernel
+        auto ln_input = [&](const bf16_t* hsrc, const std::string& norm, int ldh = 0) -> const bf16_t* {      // plain path: LN kernel
             if (fl) return hsrc;
             bf16_t* y = buf(d);
-            op_ln(hsrc, wf(t + norm + ".weight"), wf(t + norm + ".bias"), y, M, d);
+            op_ln(hsrc, wf(t + norm + ".weight"), wf(t + norm + ".bias"), y, M, d, ldh);
             return y;
         };
+        const bool mf = !fl && ffm_w.count(p);              // FF2 + proj_out as one GEMM over [gg | h2]
+        bf16_t* cat5 = mf ? buf(5 * d) : nullptr;
         bf16_t* h0 = buf(d);
         { Epi e; e.bias = wf(p + ".proj_in.bias"); e.stat_out = st0; op_linear(g, d, M, d, wb(p + ".proj_in.weight"), d, e, h0, d); }
         // self attention
@@ -680,20 +696,27 @@ struct mkd_ctx {
         kv.p += (size_t)b0 * ctx_len() * kv.ld;
         bf16_t* a2 = buf(d);
         op_attn(q2, d, kv.p, 2 * d, kv.p + d, 2 * d, a2, d, x.B, T, ctx_len(), heads, dh);
-        bf16_t* h2 = buf(d);
+        bf16_t* h2 = mf ? cat5 + 4 * d : buf(d);
+        const int ldh2 = mf ? 5 * d : d;
         { Epi e; e.bias = wf(t + ".attn2.to_out.0.bias"); e.R = h1; e.ldr = d; e.stat_out = st2;
-          op_linear(a2, d, M, d, wb(t + ".attn2.to_out.0.weight"), d, e, h2, d); }
+          op_linear(a2, d, M, d, wb(t + ".attn2.to_out.0.weight"), d, e, h2, ldh2); }
         // GEGLU feed-forward: Linear(d, 8d) + GEGLU in one GEMM (epilogue writes a * gelu(gate), 4d columns)
-        bf16_t* gg = buf(4 * d);
-        { Epi e; const bf16_t* a_in = ln_input(h2, ".norm3"); e.act = 2;
+        bf16_t* gg = mf ? cat5 : buf(4 * d);
+        const int ldg = mf ? 5 * d : 4 * d;
+        { Epi e; const bf16_t* a_in = ln_input(h2, ".norm3", ldh2); e.act = 2;
           if (fl) { e.bias = ffg_b.at(p); e.ln_s = ffg_s.at(p); e.stat_in = st2; e.stat_slots = slots; }
           else e.bias = ffp_b.at(p);
-          op_linear(a_in, d, M, d, fl ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, 4 * d); }
-        bf16_t* h3 = buf(d);
-        { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
-          op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
-        { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld;
-          op_linear(h3, d, M, d, wb(p + ".proj_out.weight"), d, e, out, ldo); }
+          op_linear(a_in, d, M, d, fl ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, ldg); }
+        if (mf) {
+            Epi e; e.bias = ffm_b.at(p); e.R = x.p; e.ldr = x.ld;
+            op_linear(cat5, 5 * d, M, 5 * d, ffm_w.at(p), d, e, out, ldo);
+        } else {
+            bf16_t* h3 = buf(d);
+            { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
+              op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
+            { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld;
+              op_linear(h3, d, M, d, wb(p + ".proj_out.weight"), d, e, out, ldo); }
+        }
         TA().release(mk);
     }
 

@@ -306,6 +306,27 @@ __global__ void clip_embed_kernel(const int32_t* __restrict__ tokens, const bf16
     }
 }
 
+// Load-time fold of the transformer's last two linear maps: out = proj_out(h2 + FF2(gg)) + x_in
+//   = [gg | h2] . [P.W2 | P]^T + (P.b2 + bp) + x_in      (P = proj_out [d,d], W2 = ff.net.2 [d,4d]; fp32 product, bf16 result)
+__global__ void merge_ff_out_kernel(const float* __restrict__ P, const float* __restrict__ W2, const float* __restrict__ b2,
+                                    const float* __restrict__ bp, bf16_t* __restrict__ Wm, float* __restrict__ bias_m, int d) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K4 = 4 * d;
+    if (k < K4) {
+        float a = 0.f;
+        for (int j = 0; j < d; ++j) a += P[(size_t)n * d + j] * W2[(size_t)j * K4 + k];
+        Wm[(size_t)n * 5 * d + k] = f32_to_bf16(a);
+    } else if (k < 5 * d) {
+        Wm[(size_t)n * 5 * d + k] = f32_to_bf16(P[(size_t)n * d + (k - K4)]);
+    }
+    if (k == 0) {
+        float a = bp[n];
+        for (int j = 0; j < d; ++j) a += P[(size_t)n * d + j] * b2[j];
+        bias_m[n] = a;
+    }
+}
+
 __global__ void copy_strided_kernel(const bf16_t* __restrict__ src, int ld_src, bf16_t* __restrict__ dst, int ld_dst,
                                     int rows, int cols) {
     const int vper = cols >> 3;
@@ -422,6 +443,13 @@ int launch_clip_embed(const int32_t* tokens, const bf16_t* tok_emb, const bf16_t
     hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for((int64_t)batch * T * (width / 8))), dim3(256), 0, stream, tokens, tok_emb, pos_emb,
                        out, batch * T, T, width, vocab);
     MKD_LAUNCH_CHECK("clip_embed_kernel");
+    return 0;
+}
+
+int launch_merge_ff_out(const float* P, const float* W2, const float* b2, const float* bp, bf16_t* Wm, float* bias_m, int d,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(merge_ff_out_kernel, dim3((5 * d + 255) / 256, d), dim3(256), 0, stream, P, W2, b2, bp, Wm, bias_m, d);
+    MKD_LAUNCH_CHECK("merge_ff_out_kernel");
     return 0;
 }
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        bf16_t* __restrict__ y, int rows, int d) {
+                                                        bf16_t* __restrict__ y, int rows, int d, int ldx) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     for (int i = 0; i < NV; ++i) {
         const int v = lane + 64 * i;
         if (v < V) {
-            const U16x8 t = *(const U16x8*)(x + (size_t)row * d + v * 8);
+            const U16x8 t = *(const U16x8*)(x + (size_t)row * ldx + v * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { f[i][j] = bf16_to_f32(t.v[j]); s += f[i][j]; }
         } else {
@@ -446,14 +446,15 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
 }
 
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
-                     int rows, int d, hipStream_t stream) {
-    if (d % 8) return mkd_fail(-1, "layernorm: d must be a multiple of 8");
+                     int rows, int d, hipStream_t stream, int ldx) {
+    if (ldx <= 0) ldx = d;
+    if (d % 8 || ldx % 8) return mkd_fail(-1, "layernorm: d and the row stride must be multiples of 8");
     const int V = d / 8;
     dim3 grid((rows + 3) / 4);
-    if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
-    else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
-    else if (V <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
-    else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d);
+    if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
+    else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
+    else if (V <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
+    else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
     else return mkd_fail(-4, "layernorm: d > 2048 unsupported");
     MKD_LAUNCH_CHECK("layernorm_kernel");
     return 0;

@@ -117,7 +117,9 @@ size_t groupnorm_partials_bytes(int batch, int hw, int groups);
 int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
                           bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream);
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
-                     int rows, int d, hipStream_t stream);
+                     int rows, int d, hipStream_t stream, int ldx = 0);      // ldx: input row stride (0 = d); y is dense
+int launch_merge_ff_out(const float* P, const float* W2, const float* b2, const float* bp, bf16_t* Wm, float* bias_m, int d,
+                        hipStream_t stream);
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
                      hipStream_t stream, int causal = 0);
