@@ -78,7 +78,8 @@ struct Op {
     double flops = 0;
     int launches = 0;
     std::string label;
-    int sid = 0;            // 0: caller's stream, 1: the context's side stream (ControlNet branch)
+    int sid = 0;            // 0: caller's stream, 1..3: side streams, HELPER_BASE + k: helper work on side stream k
+    int cap_sid = -1;       // stream while a hipGraph is being captured (-1: same)
 };
 
 // kinds: [0, 20) conv GEMM by tile config, [20, 40) linear GEMM by tile config, then the rest
@@ -128,24 +129,28 @@ struct mkd_ctx {
     float scales[64];
     int n_ctrl() const { return (int)encoder_spec().size() + 1; }
     static constexpr int NS = 4;              // streams / temp arenas: 0 = caller's stream, 1..3 = side streams
-    static constexpr int SID_HELPER = 8;      // decoder helper GEMMs: side stream 1 unless capturing (arena 1)
+    static constexpr int HELPER_BASE = 16;    // sid HELPER_BASE + k: decoder helper GEMMs on side stream k (arena k); while capturing a
+                                              // graph they run on their lane's own stream (Op::cap_sid)
+    int lane_main = 0, helper_stream = 1;     // the lane being emitted and the stream its helpers use
+    int cur_cap_sid = -1;
     static constexpr int SID_AUX = 4;         // first-stage decoder / text encoder plans: private workspaces, so that they may run
                                               // on another stream concurrently with an evaluation (pipelined decode)
     static constexpr int NA = NS + 1;         // workspace sets: one per stream + SID_AUX
     Arena persist, temp_arena[NA];
     int cur_sid = 0;
-    static int arena_of(int sid) { return sid == SID_HELPER ? 1 : sid; }
+    static int arena_of(int sid) { return sid >= HELPER_BASE ? sid - HELPER_BASE : sid; }
     Arena& TA() { return temp_arena[arena_of(cur_sid)]; }
     char* persist_base = nullptr; char* temp_base[NA] = {};
     size_t persist_cap = 0, temp_cap[NA] = {};
     float* splitk_ws[NA] = {}; size_t splitk_ws_bytes[NA] = {}, splitk_need = 0;
     float* gn_ws[NA] = {}; size_t gn_ws_bytes[NA] = {}, gn_need = 0;
     hipStream_t side_streams[NS] = {};        // [0] unused (the caller's stream)
-    hipStream_t stream_of(int sid) const { return (sid == 0 || run_serial) ? run_main : side_streams[sid == SID_HELPER ? 1 : sid]; }
+    hipStream_t stream_of(int sid) const { return (arena_of(sid) == 0 || run_serial) ? run_main : side_streams[arena_of(sid)]; }
     hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
     // measured at batch 8, 256x256 (ms per evaluation): no lanes 6.78, 2 decoder lanes 6.58, 4 decoder lanes 6.89, encoder lanes
     // on top +0.25: the encoder phase already runs two nets side by side, a third and fourth stream only add contention
     int dec_lanes = getenv("MKD_DEC_LANES") ? atoi(getenv("MKD_DEC_LANES")) : 2;          // 0 / 2 / 4 half- or quarter-batch decoder lanes
+    bool lane_helpers = getenv("MKD_LANE_HELPERS") ? atoi(getenv("MKD_LANE_HELPERS")) != 0 : false;   // 2 lanes + a helper stream each
     int dec_lanes_from = getenv("MKD_DEC_LANES_FROM") ? atoi(getenv("MKD_DEC_LANES_FROM")) : 0;   // deepest blocks as one full-batch chain first
     bool enc_lanes = getenv("MKD_ENC_LANES") ? atoi(getenv("MKD_ENC_LANES")) != 0 : false;
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
@@ -536,7 +541,7 @@ struct mkd_ctx {
     void push(std::vector<Op>& plan, OpFn f, int launches, double flops, int kind = K_MISC, const std::string& label = "") {
         if (counting_eps) { launches_eps += launches; flops_eps += flops; }
         if (!dry) {
-            Op o; o.fn = std::move(f); o.kind = kind; o.flops = flops; o.launches = launches; o.label = label; o.sid = cur_sid;
+            Op o; o.fn = std::move(f); o.kind = kind; o.flops = flops; o.launches = launches; o.label = label; o.sid = cur_sid; o.cap_sid = cur_cap_sid;
             plan.push_back(std::move(o));
         }
     }
@@ -621,11 +626,11 @@ struct mkd_ctx {
         Tensor t4;
         if (x.C != cout && side_skip) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
-            op_edge(0, 1);                               // side waits for the block input (written on main)
-            cur_sid = dec_overlap ? SID_HELPER : 0;
+            op_edge(lane_main, helper_stream);           // helper stream waits for the block input (written on the lane's stream)
+            cur_sid = HELPER_BASE + helper_stream; cur_cap_sid = lane_main;
             Epi es; es.bias = wf(p + ".skip_connection.bias");
             op_linear(x.p, x.ld, rows, x.C, wb(p + ".skip_connection.weight"), cout, es, t4.p, t4.ld);
-            cur_sid = 0;
+            cur_sid = lane_main; cur_cap_sid = -1;
         }
         Tensor t1 = talloc(TA(), x.B, x.H, x.W, x.C);
         op_gn(x, wf(p + ".in_layers.0.weight"), wf(p + ".in_layers.0.bias"), 1e-5f, 1, t1.p, t1.ld);
@@ -636,7 +641,7 @@ struct mkd_ctx {
         op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
         Epi e2; e2.bias = wf(p + ".out_layers.3.bias");
         if (x.C != cout && side_skip) {
-            op_edge(1, 0);                               // main waits for the skip GEMM
+            op_edge(helper_stream, lane_main);           // the lane waits for the skip GEMM
             e2.R = t4.p; e2.ldr = t4.ld;
         } else if (x.C != cout) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
@@ -922,7 +927,8 @@ struct mkd_ctx {
         // blocks [i0, i1); first_combined: block i0's concat input was already completed by the previous phase
         auto emit_decoder = [&](int b0, int nb, bool helpers_on_side, size_t i0, size_t i1, bool first_combined) {
             const int main_sid = cur_sid;
-            const int help_sid = helpers_on_side ? SID_HELPER : main_sid;
+            const int help_sid = helpers_on_side ? HELPER_BASE + helper_stream : main_sid;
+            const int help_cap = helpers_on_side ? main_sid : -1;
             auto combine = [&](size_t i) {          // emits on the CURRENT sid
                 const BlockSpec& bs = dec[i];
                 const int si = n_skip - 1 - (int)i;
@@ -947,14 +953,14 @@ struct mkd_ctx {
                     op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
                 }
             };
-            if (helpers_on_side) op_edge(0, 1);     // side: both encoders are complete (main already joined the ControlNet)
-            if (!first_combined) { cur_sid = help_sid; combine(i0); cur_sid = main_sid; }
+            if (helpers_on_side) op_edge(main_sid, helper_stream);     // helper: both encoders are complete (joined on the lane's stream)
+            if (!first_combined) { cur_sid = help_sid; cur_cap_sid = help_cap; combine(i0); cur_sid = main_sid; cur_cap_sid = -1; }
             Tensor cat;
             for (size_t i = i0; i < i1; ++i) {
                 const BlockSpec& bs = dec[i];
                 cat = slice(cats[i], b0, nb);
-                if (helpers_on_side) op_edge(1, 0);  // main: this block's concat input is complete
-                if (i + 1 < dec.size()) { cur_sid = help_sid; combine(i + 1); cur_sid = main_sid; }   // next block's combine runs under this block
+                if (helpers_on_side) op_edge(helper_stream, main_sid);  // lane: this block's concat input is complete
+                if (i + 1 < dec.size()) { cur_sid = help_sid; cur_cap_sid = help_cap; combine(i + 1); cur_sid = main_sid; cur_cap_sid = -1; }   // next block's combine runs under this block
                 // where does this block's output go?  next concat buffer's h half (or the final tensor)
                 const std::string p = P + "output_blocks." + std::to_string(i);
                 const Tensor nxt = slice(i + 1 < dec.size() ? cats[i + 1] : final_t, b0, nb);
@@ -1016,7 +1022,10 @@ struct mkd_ctx {
             for (int l = 0; l < DL; ++l) {
                 const int b0 = (int)((int64_t)B * l / DL), b1 = (int)((int64_t)B * (l + 1) / DL);
                 cur_plan = &lane_ops[l]; cur_sid = l;
-                emit_decoder(b0, b1 - b0, false, from, dec.size(), from > 0);
+                const bool lh = lane_helpers && DL == 2;          // lane l's helper GEMMs on stream 2 + l
+                lane_main = l; helper_stream = lh ? 2 + l : 1;
+                emit_decoder(b0, b1 - b0, lh, from, dec.size(), from > 0);
+                lane_main = 0; helper_stream = 1;
             }
             cur_plan = &plan_eps; cur_sid = 0;
             for (int l = 1; l < DL; ++l) op_edge(0, l, true, true);     // lanes start after the encoders (all joined on main)
@@ -1105,7 +1114,7 @@ struct mkd_ctx {
         io_x = x; io_t = t; io_out = out;
         run_main = stream; run_serial = !dual_stream;
         for (auto& op : plan_eps) {
-            const int sid = (op.sid == SID_HELPER && capturing) ? 0 : op.sid;
+            const int sid = (capturing && op.cap_sid >= 0) ? op.cap_sid : op.sid;
             int rc = op.fn(stream_of(sid));
             if (rc) return rc;
         }
