@@ -1,0 +1,106 @@
+"""BASELINE-size (1.22 G parameter nets, batch 8, 256x256 and 512x512) checks through properties that need no oracle run at
+that size (SURVEY.md §8c identities), plus one oracle comparison at 512x512 (B = 1).  Weights: seeded, generated on the device."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
+from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.float().cpu(); b = b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.fixture(scope='module')
+def full():
+    eng = MkdEngine(NetConfig())
+    eng.init_random(0)
+    g = torch.Generator().manual_seed(7)
+    B = 8
+    inp = dict(x=torch.randn(B, 4, 32, 32, generator=g), hint=torch.rand(B, 6, 256, 256, generator=g),
+               ctx=torch.randn(B, 77, 768, generator=g), t=torch.tensor([981, 901, 701, 501, 401, 301, 101, 1]))
+    yield eng, inp
+    eng.close()
+
+
+def test_full_size_batch8_identities(full):
+    """config 2 (batch 8, 256x256): repeatability; per-sample independence (batch 8 == the same samples evaluated as 8 x batch 1
+    and as 3 + 5, i.e. other lane splits and other tile tables, within the bf16 budget); control_scales = 0 == c_concat None
+    BIT FOR BIT (the combine epilogue computes 0 * (zero_conv + b) + skip); only_mid_control leaves the 12 skip residuals out."""
+    eng, I = full
+    eng.prepare(I['hint'], I['ctx'])
+    a = eng.eps(I['x'], I['t'])
+    assert torch.isfinite(a).all() and torch.equal(a, eng.eps(I['x'], I['t']))
+    parts = []
+    for lo, hi in ((0, 3), (3, 8)):
+        eng.prepare(I['hint'][lo:hi], I['ctx'][lo:hi])
+        parts.append(eng.eps(I['x'][lo:hi], I['t'][lo:hi]))
+    assert rel(torch.cat(parts), a) <= 2e-2
+    singles = []
+    for i in range(8):
+        eng.prepare(I['hint'][i:i + 1], I['ctx'][i:i + 1])
+        singles.append(eng.eps(I['x'][i:i + 1], I['t'][i:i + 1]))
+    assert rel(torch.cat(singles), a) <= 2e-2
+    eng.prepare(None, I['ctx'], latent_hw=(32, 32))
+    noctl = eng.eps(I['x'], I['t'])
+    eng.prepare(I['hint'], I['ctx'], control_scales=[0.0] * 13)
+    assert torch.equal(eng.eps(I['x'], I['t']), noctl)
+    assert rel(noctl, a) > 5e-2                                    # the control branch does matter with these weights
+    eng.prepare(I['hint'], I['ctx'], only_mid_control=True)
+    mid = eng.eps(I['x'], I['t'])
+    eng.prepare(I['hint'], I['ctx'], control_scales=[0.0] * 12 + [1.0])
+    assert torch.equal(eng.eps(I['x'], I['t']), mid)               # only the middle residual is injected either way
+
+
+def test_full_size_cfg_and_loop_properties(full):
+    """50-step loop at batch 8: finite, repeatable, graph replay == step-by-step launch; guidance scale 1 with an uncond batch
+    == the cond-only loop (cddim.py:15-16 vs :18-40); CFG batches uncond first."""
+    eng, I = full
+    sch = DDIMSchedule().make_ddim(50)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    eng.prepare(I['hint'], I['ctx'])
+    a = eng.sample(I['x'], *args, use_graph=False)
+    b = eng.sample(I['x'], *args, use_graph=True)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    g = torch.Generator().manual_seed(9)
+    uctx = torch.randn(8, 77, 768, generator=g)
+    eng.prepare(torch.cat([I['hint'], I['hint']]), torch.cat([uctx, I['ctx']]))
+    c = eng.sample(I['x'], *args, cfg_scale=1.0000001, use_graph=True)     # CFG path, u + s (c - u) with s ~ 1
+    cos = torch.nn.functional.cosine_similarity(c.flatten().float().cpu(), a.flatten().float().cpu(), dim=0).item()
+    assert cos >= 0.99, cos                                                 # 50 steps of bf16 drift between two batch shapes
+    d = eng.sample(I['x'], *args, cfg_scale=9.0, use_graph=True)
+    assert torch.isfinite(d).all() and rel(d, a) > 1e-2
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_512_eps_vs_oracle():
+    """config 4 geometry (512x512 -> 64x64 latent, 4096-token self-attention in the 8-wave kernel), B = 1, vs the fp32 oracle."""
+    from oracle import nets, sampler
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    cfg = nets.FULL
+    sd = nets.init_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 4, 64, 64, generator=gen); hint = torch.rand(1, 6, 512, 512, generator=gen)
+    ctx = torch.randn(1, 77, 768, generator=gen); t = torch.tensor([301])
+    ref = sampler.apply_model(sd, cfg, x, t, {'c_crossattn': [ctx], 'c_concat': [hint]})
+    eng = MkdEngine(NetConfig())
+    eng.load_state_dict(sd)
+    del sd
+    eng.prepare(hint, ctx)
+    out = eng.eps(x, t)
+    r = rel(out, ref)
+    cos = torch.nn.functional.cosine_similarity(out.flatten().float().cpu(), ref.flatten(), dim=0).item()
+    print(f'512x512 eps: rel-L2 {r:.4e} cos {cos:.6f}')
+    assert torch.isfinite(out).all() and r <= 2e-2 and cos >= 0.9995, (r, cos)
+    # 543.40 GMAC per sample per eval at 64x64 latents, minus the cached hint block (7.47) and cross-attention
+    # K/V projections (2.16): 533.77 executed
+    assert abs(eng.eps_flops() / 2e9 - 533.77) < 0.2, eng.eps_flops() / 2e9
+    eng.close()
