@@ -129,7 +129,8 @@ __global__ __launch_bounds__(512) void conv3x3_fewin_kernel(const float* __restr
                                                             const bf16_t* __restrict__ add, int act, int batch, int H, int W,
                                                             int Cout, int pix_per_block) {
     constexpr int KK = 9 * CIN;
-    __shared__ float patch[2][KK];
+    constexpr int PPB_MAX = 16;
+    __shared__ float patch[PPB_MAX][KK];
     const int co = threadIdx.x;
     const bool live = co < Cout;
     float wr[KK];
@@ -139,33 +140,30 @@ __global__ __launch_bounds__(512) void conv3x3_fewin_kernel(const float* __restr
     const int npix = batch * H * W;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(npix, p0 + pix_per_block);
-    auto load_patch = [&](int pix, int slot) {
-        if (threadIdx.x < KK) {
-            const int tap = threadIdx.x / CIN, ci = threadIdx.x - tap * CIN;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int b = pix / (H * W);
-            const int rem = pix - b * H * W;
-            const int oy = rem / W, ox = rem - oy * W;
-            const int iy = oy + ky - 1, ix = ox + kx - 1;
-            float v = 0.f;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((size_t)b * CIN + ci) * H + iy) * W + ix];
-            patch[slot][threadIdx.x] = v;
-        }
-    };
-    if (p0 < p1) load_patch(p0, 0);
+    // every input patch of the block's pixels in ONE round of loads (a per-pixel prefetch only covers one iteration, ~0.1 us,
+    // of a ~1 us load latency: the old loop paid that latency per pixel)
+    for (int idx = threadIdx.x; idx < (p1 - p0) * KK; idx += blockDim.x) {
+        const int pp = idx / KK, k = idx - pp * KK;
+        const int tap = k / CIN, ci = k - tap * CIN;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int pix = p0 + pp;
+        const int b = pix / (H * W);
+        const int rem = pix - b * H * W;
+        const int oy = rem / W, ox = rem - oy * W;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((size_t)b * CIN + ci) * H + iy) * W + ix];
+        patch[pp][k] = v;
+    }
     __syncthreads();
+    if (!live) return;
     for (int pix = p0; pix < p1; ++pix) {
-        const int slot = (pix - p0) & 1;
-        if (pix + 1 < p1) load_patch(pix + 1, slot ^ 1);
         float acc = bz;
 #pragma unroll
-        for (int k = 0; k < KK; ++k) acc += patch[slot][k] * wr[k];
-        if (live) {
-            if (act == 1) acc = silu_f(acc);
-            if (add) acc += bf16_to_f32(add[(size_t)pix * Cout + co]);
-            y[(size_t)pix * Cout + co] = f32_to_bf16(acc);
-        }
-        __syncthreads();
+        for (int k = 0; k < KK; ++k) acc += patch[pix - p0][k] * wr[k];
+        if (act == 1) acc = silu_f(acc);
+        if (add) acc += bf16_to_f32(add[(size_t)pix * Cout + co]);
+        y[(size_t)pix * Cout + co] = f32_to_bf16(acc);
     }
 }
 
@@ -392,7 +390,7 @@ int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const
     if (stride != 1 && stride != 2) return mkd_fail(-1, "conv3x3_direct: stride must be 1 or 2");
     if (in_nchw_f32 && !out_nchw_f32 && stride == 1 && Cin == 4 && Cout >= 64 && Cout <= 512) {
         const int npix = batch * Hin * Win;
-        const int ppb = 8;
+        const int ppb = 16;            // <= PPB_MAX of the kernel
         const int threads = (Cout + 63) / 64 * 64;
         hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, dim3((npix + ppb - 1) / ppb), dim3(threads), 0, stream, (const float*)x, w, bias,
                            (bf16_t*)y, add, act, batch, Hin, Win, Cout, ppb);
