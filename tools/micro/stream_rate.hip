@@ -12,14 +12,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const char* __restrict__ sr
     __shared__ __attribute__((aligned(16))) char lds[DEPTH * 16384];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // tile step = 128 rows x 128 B (16 KB): thread -> (row = tid/8 + 32*i, chunk = tid%8), rows row_stride bytes apart
-    const char* base = src + (size_t)blockIdx.x * rows * row_stride;
+    const char* base = src + (size_t)blockIdx.x * (row_stride == 128 ? bytes_per_wg : (size_t)rows * row_stride);
     const int steps = (int)(bytes_per_wg / 16384);
+    const size_t step_bytes = row_stride == 128 ? 16384 : 128;      // pre-tiled: next step = next 16 KB block
     f32x4 acc = {0, 0, 0, 0};
     if (MODE == 0) {
         for (int s = 0; s < steps; ++s) {
             f32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)(base + (size_t)((tid >> 3) + 32 * i) * row_stride + (size_t)s * 128 + (tid & 7) * 16);
+            for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)(base + (size_t)((tid >> 3) + 32 * i) * row_stride + (size_t)s * step_bytes + (tid & 7) * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc += v[i];
         }
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const char* __restrict__ sr
             char* dst = lds + (s % DEPTH) * 16384;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const char* g = base + (size_t)((tid >> 3) + 32 * i) * row_stride + (size_t)s * 128 + (tid & 7) * 16;
+                const char* g = base + (size_t)((tid >> 3) + 32 * i) * row_stride + (size_t)s * step_bytes + (tid & 7) * 16;
                 __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(dst + (w * 4 + i) * 1024), 16, 0, 0);
             }
         };
@@ -48,14 +49,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const char* __restrict__ sr
 template <int NT>
 __global__ __launch_bounds__(NT) void stream_vgpr_nt(const char* __restrict__ src, size_t bytes_per_wg, float* sink, int row_stride, int rows) {
     const int tid = threadIdx.x;
-    const char* base = src + (size_t)blockIdx.x * rows * row_stride;
+    const char* base = src + (size_t)blockIdx.x * (row_stride == 128 ? bytes_per_wg : (size_t)rows * row_stride);
     const int steps = (int)(bytes_per_wg / 16384);
+    const size_t step_bytes = row_stride == 128 ? 16384 : 128;
     constexpr int RPT = 128 / (NT / 8);
     f32x4 acc = {0, 0, 0, 0};
     for (int s = 0; s < steps; ++s) {
         f32x4 v[RPT];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) v[i] = *(const f32x4*)(base + (size_t)((tid >> 3) + (NT / 8) * i) * row_stride + (size_t)s * 128 + (tid & 7) * 16);
+        for (int i = 0; i < RPT; ++i) v[i] = *(const f32x4*)(base + (size_t)((tid >> 3) + (NT / 8) * i) * row_stride + (size_t)s * step_bytes + (tid & 7) * 16);
 #pragma unroll
         for (int i = 0; i < RPT; ++i) acc += v[i];
     }
@@ -68,11 +70,11 @@ int main() {
     hipMalloc(&buf, total); hipMalloc(&sink, 64); hipMemset(buf, 1, total);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int rows = 128;
-    for (int row_stride : {2560}) {
-        for (int nwg : {64, 80, 256, 512, 1024}) {
-            const size_t per_row = (size_t)row_stride;                 // bytes available per row
-            const size_t bytes_per_wg = (size_t)rows * per_row;        // one pass over the WG's 128 rows
-            if ((size_t)nwg * bytes_per_wg > total) continue;
+    for (int row_stride : {2560, 128, 640, 23040}) {      // 128: each 16 KB step fully contiguous (a pre-tiled operand)
+        for (int nwg : {80, 256}) {
+            // one pass over the WG's 128 rows (2560 B of each row are read; with stride 128 the steps are consecutive 16 KB blocks)
+            const size_t bytes_per_wg = (size_t)rows * 2560;
+            if ((size_t)nwg * (size_t)rows * (row_stride > 2560 ? row_stride : 2560) > total) continue;
             auto run = [&](int mode, int depth) {
                 float best = 1e9;
                 for (int r = 0; r < 5; ++r) {
