@@ -142,6 +142,8 @@ def main():
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--cfg', action='store_true', help='classifier-free guidance 9.0 (2 evals / step)')
+    ap.add_argument('--interp', type=int, default=0, metavar='N_ALPHA',
+                    help='BASELINE config 5: makeup interpolation sweep, --batch SOURCES per GPU x N_ALPHA alpha points (two references)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-evals', type=int, default=2)
     ap.add_argument('--graph', type=int, default=1, help='replay the DDIM step as a hipGraph (0 = eager launches)')
@@ -172,12 +174,26 @@ def main():
     n_total = B * world
     lo, hi = mdist.shard_range(n_total, rank, world)
     x_T, hint, ctx, uctx = synth_inputs(lo, hi, args.res, cfg.context_dim, dev)
+    hint2 = alpha = None
+    if args.interp:
+        # every source is sampled at every alpha from the same start noise; E = (1 - a) E(src||ref1) + a E(src||ref2)
+        k = args.interp
+        _, other, _, _ = synth_inputs(lo + 100000, hi + 100000, args.res, cfg.context_dim, dev)
+        hint2 = torch.cat([hint[:, :3], other[:, 3:]], 1)                       # same source, second reference
+        rep = lambda t: t.repeat_interleave(k, 0)
+        x_T, hint, hint2, ctx = rep(x_T), rep(hint), rep(hint2), rep(ctx)
+        alpha = torch.linspace(0.0, 1.0, k, device=dev).repeat(B)
+        B = B * k; n_total = n_total * k
     sch = DDIMSchedule().make_ddim(args.ddim_steps)
+    if args.interp and args.cfg:
+        raise SystemExit('--interp and --cfg are separate workloads')
     cfg_scale = 9.0 if args.cfg else 1.0
 
     def one_step():
         if args.cfg:       # uncond first (cddim.py:25-31), same hint (diffusion_makeup.py:401)
             eng.prepare(torch.cat([hint, hint]), torch.cat([uctx, ctx]))
+        elif args.interp:
+            eng.prepare(hint, ctx, hint2=hint2, alpha=alpha)
         else:
             eng.prepare(hint, ctx)
         lat = eng.sample(x_T, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
@@ -238,6 +254,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'batch={B}/GPU {args.res}x{args.res}, {args.ddim_steps} DDIM steps, eta 0, '
+                                   + (f'makeup interpolation sweep: {args.batch} sources x {args.interp} alpha, ' if args.interp else '')
                                    + ('CFG 9.0 (2 evals/step)' if args.cfg else 'no CFG (1 eval/step)')
                                    + ', ControlNet+UNet every step, random-init SD-1.5 ControlNet weights, '
                                    + ('VAE-decoded images out' if args.decode else 'latents out'),
