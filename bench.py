@@ -5,8 +5,11 @@
 
 One "step" = one pass of the hot path over one batch: mkd_prepare (hint embedding + cross-attn K/V caches)
 + the full 50-step DDIM reverse loop x_T -> latent (ControlNet + UNet every step), inputs resident in HBM.
-N > 1: launched by torch.distributed.run, one rank per GPU, batch-sharded replicas (weak scaling, B per GPU
-fixed), a single RCCL all-gather of the finished latents per step.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU, batch-sharded replicas (weak scaling, B per GPU fixed), a single RCCL all-gather of the finished
+images per step.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment) or by itself: a plain
+`python bench.py --gpus N` starts its N ranks as fresh child processes before touching the GPU.  With fewer than N devices
+visible the N ranks share card 0 over gloo (a REHEARSAL of the N > 1 code path, flagged in the JSON, not a measurement).
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -151,9 +154,20 @@ def main():
     ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # self-launch: nothing in this process has touched the GPU (device_count() does not initialise HIP on this image)
+        extra = {}
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            if args.gpus > 6:
+                raise SystemExit(f'--gpus {args.gpus} with {ndev} device(s) visible: a rehearsal on one card is limited to 6 ranks')
+            log(f'{ndev} device(s) visible for --gpus {args.gpus}: REHEARSAL on card 0 over gloo (code path only, not a measurement)')
+            extra = {'MKD_BENCH_SINGLE_DEVICE': '1', 'MKD_DIST_BACKEND': 'gloo'}
+        raise SystemExit(mdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, extra))
     rank, world, local = mdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                         f'or without WORLD_SIZE set (bench.py then starts its own ranks)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU path for the product)')
     if os.environ.get('MKD_BENCH_SINGLE_DEVICE') == '1':      # rehearsal of the N>1 path on a 1-GPU box (with MKD_DIST_BACKEND=gloo)
@@ -165,7 +179,7 @@ def main():
     eng = MkdEngine(cfg, dev)
     if args.decode:
         eng.configure_vae(VaeConfig())
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_cpu = rank == 0 and not args.no_cpu_baseline
     log(f'rank {rank}/{world}: generating 1.22 G synthetic weights on {dev}')
     sd_cpu = gen_weights(eng, seed=0, keep_cpu=want_cpu)
     log('weights loaded')
@@ -219,6 +233,13 @@ def main():
     assert torch.isfinite(out).all(), 'non-finite latents'
     log(f'timed {args.steps} steps in {dt:.2f} s')
 
+    # which device every rank ran on (gathered over the process group: shows N distinct GPUs, or one in a rehearsal)
+    me = f'{torch.cuda.get_device_name(local)} #{local}' + (f' pci {torch.cuda.get_device_properties(local).pci_bus_id}'
+                                                               if hasattr(torch.cuda.get_device_properties(local), 'pci_bus_id') else '')
+    dev_names = [me]
+    if world > 1:
+        dev_names = [None] * world
+        torch.distributed.all_gather_object(dev_names, me)
     if rank == 0:
         evals_per_step = args.ddim_steps
         eps_flops = eng.eps_flops()                      # executed FLOPs of one eval at the prepared batch
@@ -259,6 +280,11 @@ def main():
                                    + ', ControlNet+UNet every step, random-init SD-1.5 ControlNet weights, '
                                    + ('VAE-decoded images out' if args.decode else 'latents out'),
                        'global_batch': n_total, 'parallelism': f'batch-shard x{world}, 1 all-gather/step'},
+            # evidence of the N > 1 run: what the process group itself reports
+            'ranks_seen': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+            'rehearsal_single_device': os.environ.get('MKD_BENCH_SINGLE_DEVICE') == '1',
+            'devices': sorted(set(dev_names)),
             'roofline': roofline,
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,

@@ -14,6 +14,7 @@ TARGET_ALIASES = {
     'diffmk.diffusion_makeup.TestDoubleControlModel': 'makeupdiffuse_amd.diffmk.diffusion_makeup.TestDoubleControlModel',
     'diffmk.makeup_diffuse.BaseMakeUpDiffuse': 'makeupdiffuse_amd.diffmk.makeup_diffuse.BaseMakeUpDiffuse',
     'diffmk.makeup_diffuse.TestDiffuseModel': 'makeupdiffuse_amd.diffmk.makeup_diffuse.TestDiffuseModel',
+    'diffmk.makeups.BaseModel': 'makeupdiffuse_amd.diffmk.makeups.BaseModel',
     'diffmk.makeup_controlnet.MakeupDoubleControlModel': 'makeupdiffuse_amd.diffmk.makeup_controlnet.MakeupDoubleControlModel',
 }
 

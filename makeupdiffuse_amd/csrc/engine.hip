@@ -556,14 +556,16 @@ struct mkd_ctx {
     void op_gemm(GemmArgs a) {
         a.zero = zero_page;
         a.splitk = 0;
-        const int s = gemm_pick_splitk(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+        int cfg_i = 0, s = 1;
+        if (gemm_resolve(a, &cfg_i, &s)) { cfg_i = 1; s = 1; }       // (an unsupported forced tile fails again, loudly, at launch)
         const size_t need = gemm_ws_bytes(a.M, a.N, s);
         if (need > splitk_need) splitk_need = need;
         mkd_ctx* self = this;
         const int sid = cur_sid;
-        push(*cur_plan, [self, a, sid](hipStream_t st) { GemmArgs b = a; b.ws = self->splitk_ws[arena_of(sid)]; return launch_gemm(b, st); },
-             s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K,
-             (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + gemm_tile_index(a.M, a.N, a.K, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0),
+        push(*cur_plan, [self, a, sid](hipStream_t st) {
+                 GemmArgs b = a; b.ws = self->splitk_ws[arena_of(sid)]; b.ws_bytes = self->splitk_ws_bytes[arena_of(sid)];
+                 return launch_gemm(b, st); },
+             s > 1 ? 2 : 1, 2.0 * a.M * a.N * a.K, (a.conv ? K_GEMM_CONV : K_GEMM_LIN) + cfg_i,
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
              " stride=" + std::to_string(a.stride) + " up=" + std::to_string(a.up) + " splitk=" + std::to_string(s) +
              " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32) + " Hin=" + std::to_string(a.Hin) +
@@ -1834,10 +1836,13 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
     a.R = R; a.ldr = ldr; a.scale = scale; a.act = act; a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K;
     a.conv = conv3x3 ? 1 : 0; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
     a.zero = g_zero;
-    int s = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K, conv3x3 ? 1 : 0, conv3x3 ? stride : 0, conv3x3 ? up : 0);
-    int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    a.splitk = splitk > 0 ? splitk : 0;
+    int cfg_i = 0, s = 1;
+    int rc = gemm_resolve(a, &cfg_i, &s);          // the decision launch_gemm will take, fallbacks included
     if (rc) return rc;
-    a.ws = g_ws; a.splitk = s;
+    rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    if (rc) return rc;
+    a.ws = g_ws; a.ws_bytes = g_ws_bytes;
     return launch_gemm(a, (hipStream_t)stream);
 }
 int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K, uint16_t* w_out,
@@ -1872,10 +1877,12 @@ int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ld
     GemmArgs a; memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.scale = 1.f; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.K = K; a.rows_per_batch = 1; a.zero = g_zero; a.stat_out = stat_out;
-    const int s = gemm_pick_splitk(M, N, K, 0, 0, 0);
-    int rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    int cfg_i = 0, s = 1;
+    int rc = gemm_resolve(a, &cfg_i, &s);
     if (rc) return rc;
-    a.ws = g_ws;
+    rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s > 1 ? s : 2));
+    if (rc) return rc;
+    a.ws = g_ws; a.ws_bytes = g_ws_bytes;
     return launch_gemm(a, (hipStream_t)stream);
 }
 int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,

@@ -302,6 +302,7 @@ int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
     const int per = (nch + s - 1) / s;
     s = (nch + per - 1) / per;
     if (s > 1 && !a.ws) return mkd_fail(-1, "conv3x3_patch: split-K needs a workspace");
+    if (s > 1 && gemm_ws_bytes(a.M, a.N, s) > a.ws_bytes) return mkd_fail(-1, "conv3x3_patch: split-K workspace too small");
     a.splitk = s;
     a.ksteps_per_split = per;
     const int groups = (batch + a.tile_imgs - 1) / a.tile_imgs;

@@ -385,10 +385,12 @@ void gemm_force_tile_cfg(int cfg) { g_force_cfg = (cfg >= 0 && cfg < N_TILE_CFG)
 // Tile + split-K choice.  Large problems take the big tiles (more FLOP per byte staged through L2 -> LDS,
 // which is what bounds these kernels); problems that cannot fill the 256 CUs step down to smaller tiles
 // and only then split K (fp32 partial slabs cost 8 B per output element per slice).
-static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, int stride = 0, int up = 0) {
+// pin_cfg >= 0: that tile configuration, split-K by the heuristic, tuned table / overrides / g_force_cfg ignored
+static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, int stride = 0, int up = 0, int pin_cfg = -1) {
     const int nk = (K + BK - 1) / BK;
     auto tiles = [&](int c) { return ((M + kTileM[c] - 1) / kTileM[c]) * ((N + kTileN[c] - 1) / kTileN[c]); };
     int cfg;
+    const int g_force_cfg = pin_cfg >= 0 ? pin_cfg : ::g_force_cfg;          // (shadows the global on purpose)
     const TunedEntry* te = (g_force_cfg < 0 && force_splitk <= 0) ? tuned_lookup(M, N, K, conv, stride, up) : nullptr;
     if (g_force_cfg < 0 && force_splitk <= 0 && !g_override.empty()) {
         auto it = g_override.find(ShapeKey{M, N, K, conv, stride, up});
@@ -445,12 +447,45 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
 }
 
 int gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up) { return gemm_plan(M, N, K, 0, conv, stride, up).splitk; }
-int gemm_max_splitk() { return 32; }
+
 // producers of fused-LayerNorm row statistics keep column tiles >= 64 wide (one statistics slot per column tile, <= 20 slots)
 static GemmPlan stat_producer_plan(GemmPlan g) {
     if (kTileN[g.cfg] < 64) g.cfg = 5;
     return g;
 }
+
+// The ONE place that decides (tile, split-K) for a launch, with the full geometry: the engine sizes its split-K workspace from
+// this at plan time and launch_gemm takes the same decision at launch time.  A tuned LDS-patch entry whose spatial tiling does
+// not fit THIS geometry (the table is keyed on M, N, K only) falls back to the generic 128x128 tile with heuristic split-K.
+static int gemm_resolve_plan(const GemmArgs& a, GemmPlan* out) {
+    GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+    if (a.ln_s && g.splitk > 1) {          // the LN correction is applied on the full-K accumulator
+        g.splitk = 1;
+        g.per = (a.K + BK - 1) / BK;
+    }
+    if (a.stat_out) g = stat_producer_plan(g);
+    if (is_patch_cfg(g.cfg) && !conv_patch_supported(a, g.cfg)) {
+        if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
+        g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0, /*pin_cfg=*/1);
+    }
+    *out = g;
+    return 0;
+}
+int gemm_resolve(const GemmArgs& a, int* cfg, int* splitk) {
+    GemmPlan g;
+    const int rc = gemm_resolve_plan(a, &g);
+    if (rc) return rc;
+    if (is_patch_cfg(g.cfg)) {             // the patch launcher splits over channel chunks and re-derives the count
+        const int nch = a.Cin / 64;
+        int s = g.splitk < 1 ? 1 : g.splitk;
+        if (s > nch) s = nch;
+        const int per = (nch + s - 1) / s;
+        g.splitk = (nch + per - 1) / per;
+    }
+    *cfg = g.cfg; *splitk = g.splitk;
+    return 0;
+}
+int gemm_max_splitk() { return 32; }
 int gemm_stat_slots(int M, int N, int K) {
     const GemmPlan g = stat_producer_plan(gemm_plan(M, N, K, 0));
     if (g.splitk > 1) return (N + 255) / 256;
@@ -502,24 +537,16 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
     if (a.ln_s && (a.conv || a.K > 8192)) return mkd_fail(-1, "gemm: fused LayerNorm is for linear GEMMs");
-    GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
     if (a.ln_s && (!a.stat_in || a.stat_in_slots <= 0 || a.stat_in_slots > 20))
         return mkd_fail(-1, "gemm: fused LayerNorm needs the producer's row statistics in 1..20 column slots");
-    if (a.ln_s && g.splitk > 1) {          // the LN correction is applied on the full-K accumulator
-        g.splitk = 1;
-        g.per = (a.K + BK - 1) / BK;
-    }
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
-    if (a.stat_out) g = stat_producer_plan(g);
-    if (is_patch_cfg(g.cfg)) {
-        if (conv_patch_supported(a, g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
-        if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
-        const int keep = g_force_cfg;                 // tuned entry from another geometry: fall back to the heuristic
-        g_force_cfg = 1;
-        g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0);
-        g_force_cfg = keep;
-    }
+    GemmPlan g;
+    { const int rc = gemm_resolve_plan(a, &g); if (rc) return rc; }
+    if (is_patch_cfg(g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
     if (g.splitk > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
+    if (g.splitk > 1 && gemm_ws_bytes(a.M, a.N, g.splitk) > a.ws_bytes)
+        return mkd_fail(-1, "gemm: split-K workspace too small (" + std::to_string(a.ws_bytes) + " B for " + std::to_string(g.splitk) + " slabs of " +
+                                std::to_string(a.M) + " x " + std::to_string(a.N) + ")");
     a.splitk = g.splitk;
     a.ksteps_per_split = g.per;
     int rc;

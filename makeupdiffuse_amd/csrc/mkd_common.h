@@ -77,7 +77,7 @@ struct GemmArgs {
     void* C; int ldc; int out_f32;
     int M, N, K;
     int conv; int Hin, Win, Cin, Hout, Wout, stride, up;
-    float* ws; int splitk; int ksteps_per_split;
+    float* ws; size_t ws_bytes; int splitk; int ksteps_per_split;     // split-K fp32 partial slabs: pointer and capacity
     int tile_h, tile_w, tile_imgs;          // spatial tile of the LDS-staged conv kernel (set by its launcher)
     const float* ln_s; float ln_eps;        // fused LayerNorm on the A rows: ln_s[n] = sum_k W'[n][k] (W' = W*gamma), else null
     const float* stat_in; int stat_in_slots; // ... whose row sums were emitted by the producer: [slots][M][2] (sum, sumsq)
@@ -97,6 +97,7 @@ struct StepState {
 // launchers (each only enqueues on `stream`)
 int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
+int  gemm_resolve(const GemmArgs& a, int* cfg, int* splitk);       // the (tile, split-K) launch_gemm will use for exactly these arguments
 int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)

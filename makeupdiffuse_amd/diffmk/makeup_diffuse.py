@@ -20,8 +20,20 @@ from ..lib import MkdError
 from ..schedule import DDIMSchedule
 
 
-def _key(t: Optional[torch.Tensor]):
-    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+class _Held:
+    """Cache key over tensors that HOLDS them: identity + in-place version.  An address-based key would match a new tensor
+    that the caching allocator placed where a freed one used to be (the next batch of a test loop: same shapes, same
+    allocation order) and silently reuse the previous batch's conditioning."""
+
+    def __init__(self, tensors, extra=()):
+        self.tensors = tuple(tensors)
+        self.versions = tuple(None if t is None else t._version for t in self.tensors)
+        self.extra = tuple(extra)
+
+    def matches(self, tensors, extra=()) -> bool:
+        tensors = tuple(tensors)
+        return (len(tensors) == len(self.tensors) and tuple(extra) == self.extra
+                and all(a is b and (a is None or a._version == v) for a, b, v in zip(tensors, self.tensors, self.versions)))
 
 
 class BaseMakeUpDiffuse:
@@ -161,27 +173,32 @@ class BaseMakeUpDiffuse:
 
     def _bind(self, hint: Optional[torch.Tensor], ctx: torch.Tensor, latent_hw) -> MkdEngine:
         eng = self._require_engine()
-        key = (_key(hint), _key(ctx), tuple(latent_hw), tuple(self.control_scales), self.only_mid_control)
-        if key != self._bound:
+        extra = (tuple(latent_hw), tuple(self.control_scales), self.only_mid_control)
+        if self._bound is None or not self._bound.matches((hint, ctx), extra):
             eng.prepare(hint, ctx, latent_hw=tuple(latent_hw), control_scales=self.control_scales,
                         only_mid_control=self.only_mid_control)
-            self._bound = key
+            self._bound = _Held((hint, ctx), extra)
         return eng
+
+    def reset_conditioning_cache(self) -> None:
+        """Drop the prepared-conditioning and CFG-merge caches (and the tensors they hold)."""
+        self._bound = None
+        self._cfg_cache = None
 
     def cfg_conditioning(self, uncond: dict, cond: dict) -> dict:
         """[uncond; cond] batching (cddim.py:18-38), cached per (uncond, cond) pair so that a step-by-step
         caller does not rebuild — and libmkd does not re-prepare — identical conditioning every step."""
         def flat(c):
-            out = []
+            out, names = [], []
             for k in sorted(c):
                 v = c[k]
                 if isinstance(v, list):
-                    out += [_key(t) for t in v]
+                    out += list(v); names.append((k, len(v)))
                 elif isinstance(v, torch.Tensor):
-                    out.append(_key(v))
-            return tuple(out)
-        key = (flat(uncond), flat(cond))
-        if self._cfg_cache is None or self._cfg_cache[0] != key:
+                    out.append(v); names.append((k, -1))
+            return out, names
+        (tu, nu), (tc, nc) = flat(uncond), flat(cond)
+        if self._cfg_cache is None or not self._cfg_cache[0].matches(tu + tc, (tuple(nu), tuple(nc))):
             merged = {}
             for k in cond:
                 if isinstance(cond[k], list):
@@ -190,7 +207,7 @@ class BaseMakeUpDiffuse:
                     merged[k] = torch.cat([uncond[k], cond[k]])
                 else:
                     merged[k] = cond[k]
-            self._cfg_cache = (key, merged)
+            self._cfg_cache = (_Held(tu + tc, (tuple(nu), tuple(nc))), merged)
         return self._cfg_cache[1]
 
     # ---- the eps model ---------------------------------------------------------------------------------------
@@ -246,6 +263,18 @@ class BaseMakeUpDiffuse:
         if eng.vae_cfg is None:
             raise NotImplementedError('no first_stage_config in the yaml: the decoder was not configured')
         return eng.decode(z, self.scale_factor)
+
+    def decode_latent_code(self, z: torch.Tensor, predict_cids: bool = False, force_not_quantize: bool = False) -> torch.Tensor:
+        """reference diffmk/makeups.py:260-262: ``first_stage_model.decode(z / scale_factor)`` (unclamped)."""
+        return self.decode_first_stage(z)
+
+    @torch.no_grad()
+    def generate_image(self, z: torch.Tensor, format: bool = False) -> torch.Tensor:
+        """reference diffmk/makeup_diffuse.py:172-177: decode, clamp to [-1, 1], optionally map to [0, 1]."""
+        img = self.decode_first_stage(z).clamp(-1, 1)
+        if format:
+            img = (img + 1.0) / 2.0
+        return img
 
     @property
     def has_first_stage(self) -> bool:
@@ -345,7 +374,7 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
                         control_scales=self.control_scales, only_mid_control=self.only_mid_control)
         else:
             eng.prepare(h1, ctxr, hint2=h2, alpha=al, control_scales=self.control_scales, only_mid_control=self.only_mid_control)
-        self._bound = None
+        self.reset_conditioning_cache()
         lat = eng.sample(x_T, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                          cfg_scale=float(unconditional_guidance_scale), use_graph=True)
         out = {'samples_latent': lat, 'alpha': al}
@@ -353,8 +382,10 @@ class TestDiffuseModel(BaseMakeUpDiffuse):
             out['samples'] = self.decode_first_stage(lat)
         return out
 
-    def test_step(self, batch: dict, batch_idx: int) -> Dict[str, torch.Tensor]:
-        images = self.log_results(batch, batch_idx)
+    def test_step(self, batch: dict, batch_idx: int, x_T: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """reference diffusion_makeup.py:332-341.  x_T (not in the reference, which always draws fresh noise): fixed start
+        noise for both sampling passes, so that runs can be compared."""
+        images = self.log_results(batch, batch_idx, x_T=x_T)
         for k in images:
             if isinstance(images[k], torch.Tensor):
                 images[k] = images[k].detach().cpu()

@@ -37,6 +37,42 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(argv, world: int, env_extra: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Start `world` FRESH child processes of `argv` (one per rank: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set, rendezvous on 127.0.0.1) and wait for them; returns the largest exit code.  The caller must not have touched the GPU:
+    children are new processes (no fork of a HIP context, no exec from an initialised process).  Rank 0 inherits stdout, so its
+    single JSON line is the launcher's output; every rank inherits stderr."""
+    import subprocess
+    import sys
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=None))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait(timeout=timeout)))
+    except BaseException:
+        for p in procs:                    # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        raise
+    finally:
+        sys.stdout.flush()
+    return rc
+
+
 def gather_shards(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """All-gather per-rank batch shards (possibly ragged by one) into the full [n_total, ...] tensor, in
     global sample order, on every rank.  Single collective: shards are padded to the largest shard."""

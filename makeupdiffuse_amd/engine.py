@@ -216,9 +216,10 @@ class MkdEngine:
             self.finalize_clip()
         return unused
 
-    def init_random(self, seed: int = 0, gain: float = 1.0) -> None:
-        """Seeded synthetic weights generated ON the device (bench only): N(0, 1/fan_in) for
-        every matrix/conv including upstream's zero-initialised ones, gamma 1 / beta 0, small biases."""
+    def init_random(self, seed: int = 0, gain: float = 1.0, norm_jitter: float = 0.0) -> None:
+        """Seeded synthetic weights generated ON the device (bench / property tests): N(0, 1/fan_in) for
+        every matrix/conv including upstream's zero-initialised ones, small biases, norm gamma = 1 + norm_jitter * N(0,1) and
+        beta = norm_jitter * N(0,1) (0: the upstream initial values gamma 1 / beta 0)."""
         g = torch.Generator(device=self.device)
         g.manual_seed(seed)
         for name, shape in self.expected_params().items():
@@ -227,6 +228,8 @@ class MkdEngine:
             if len(shape) == 1:
                 if is_norm:
                     t = (torch.ones if name.endswith('weight') else torch.zeros)(shape, device=self.device)
+                    if norm_jitter:
+                        t = t + norm_jitter * torch.randn(shape, generator=g, device=self.device)
                 else:
                     t = 0.02 * torch.randn(shape, generator=g, device=self.device)
             else:
@@ -375,7 +378,17 @@ class MkdEngine:
                sqrt_one_minus_alphas: Sequence[float], cfg_scale: float = 1.0, use_graph: bool = False) -> torch.Tensor:
         """Whole eta=0 reverse loop in one call (cddim.py:81-100). Prepared batch must be B or 2B (CFG)."""
         x_T = _f32c(x_T, self.device)
+        cfg_on = float(cfg_scale) != 1.0
+        want_b = self.batch // 2 if cfg_on else self.batch
+        if (x_T.dim() != 4 or tuple(x_T.shape[1:]) != (self.cfg.in_channels, *self.latent_hw) or x_T.shape[0] != want_b
+                or (cfg_on and self.batch % 2)):
+            # libmkd copies batch * C * h * w floats using the PREPARED h, w: a smaller latent would be read out of bounds
+            raise ValueError(f'x_T {tuple(x_T.shape)} does not match the prepared conditioning: expected '
+                             f'({want_b}, {self.cfg.in_channels}, {self.latent_hw[0]}, {self.latent_hw[1]})'
+                             + (' (CFG: prepared batch is [uncond; cond])' if cfg_on else ''))
         n = len(timesteps)
+        if n <= 0 or not (len(alphas) == len(alphas_prev) == len(sqrt_one_minus_alphas) == n):
+            raise ValueError('timesteps / alphas / alphas_prev / sqrt_one_minus_alphas must be non-empty and equally long')
         ts = (C.c_int64 * n)(*[int(v) for v in timesteps])
         a = (C.c_float * n)(*[float(v) for v in alphas])
         ap = (C.c_float * n)(*[float(v) for v in alphas_prev])

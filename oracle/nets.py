@@ -13,6 +13,7 @@ Everything is NCHW fp32 ``torch`` on the CPU, no nn.Module, no autograd.
 from __future__ import annotations
 
 import math
+import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -200,10 +201,14 @@ def full_param_spec(cfg: NetConfig) -> Dict[str, tuple]:
 
 
 def init_state_dict(cfg: NetConfig, seed: int = 0, dtype=torch.float32, device='cpu',
-                    gain: float = 1.0) -> SD:
+                    gain: float = 1.0, norm_jitter: float = 0.2) -> SD:
     """Seeded synthetic weights, SURVEY.md §8(d): N(0, 1/fan_in) for every matrix/conv
-    INCLUDING the tensors upstream zero-initialises (finding 8), norm gamma=1 beta=0,
-    small random biases.  Generated tensor-by-tensor in name order on ``device``."""
+    INCLUDING the tensors upstream zero-initialises (finding 8), small random biases.
+    Norm affine parameters are RANDOM (gamma = 1 + norm_jitter * N(0,1), beta = norm_jitter * N(0,1)),
+    each from its own name-seeded stream: a fixture built from this initialiser fails when two norms are
+    swapped (norm1/norm2/norm3, in_layers.0/out_layers.0) or a beta is dropped.  norm_jitter = 0 gives
+    the upstream initial values gamma = 1 / beta = 0 (what bench.py's synthetic weights use).
+    Generated tensor-by-tensor in name order on ``device``."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     sd: SD = {}
@@ -212,8 +217,14 @@ def init_state_dict(cfg: NetConfig, seed: int = 0, dtype=torch.float32, device='
                    or name.endswith('out.0.weight') or name.endswith('out.0.bias'))
         if len(shape) == 1:
             if is_norm:
-                t = torch.ones(shape, dtype=dtype, device=device) if name.endswith('weight') \
-                    else torch.zeros(shape, dtype=dtype, device=device)
+                base = 1.0 if name.endswith('weight') else 0.0
+                t = torch.full(shape, base, dtype=torch.float32, device=device)
+                if norm_jitter:
+                    # own generator per tensor: the matrices keep the values they had before norm_jitter existed
+                    gn = torch.Generator(device=device)
+                    gn.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+                    t = t + norm_jitter * torch.randn(shape, generator=gn, dtype=torch.float32, device=device)
+                t = t.to(dtype)
             else:
                 t = 0.02 * torch.randn(shape, generator=g, dtype=torch.float32, device=device).to(dtype)
         else:

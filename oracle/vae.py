@@ -9,6 +9,7 @@ decoder with upstream state-dict names (``first_stage_model.decoder.*``).  PARIT
 """
 from __future__ import annotations
 
+import zlib
 from dataclasses import dataclass
 from typing import Dict, Sequence
 
@@ -69,13 +70,19 @@ def param_spec(cfg: VaeConfig, prefix: str = PREFIX) -> Dict[str, tuple]:
     return d
 
 
-def init_state_dict(cfg: VaeConfig, seed: int = 0) -> Dict[str, Tensor]:
+def init_state_dict(cfg: VaeConfig, seed: int = 0, norm_jitter: float = 0.2) -> Dict[str, Tensor]:
+    """Seeded synthetic decoder weights; GroupNorm gamma = 1 + norm_jitter * N(0,1), beta = norm_jitter * N(0,1)
+    (random, so that a fixture sees a swapped or dropped norm parameter; 0 gives gamma 1 / beta 0)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for name, shape in sorted(param_spec(cfg).items()):
         if len(shape) == 1:
             if 'norm' in name:
-                sd[name] = torch.ones(shape) if name.endswith('weight') else torch.zeros(shape)
+                t = torch.ones(shape) if name.endswith('weight') else torch.zeros(shape)
+                if norm_jitter:
+                    gn = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+                    t = t + norm_jitter * torch.randn(shape, generator=gn)
+                sd[name] = t
             else:
                 sd[name] = 0.02 * torch.randn(shape, generator=g)
         else:

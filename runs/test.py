@@ -44,6 +44,8 @@ def main():
     ap.add_argument('--data-root', default=None, help='folder with images/ and a pairs file (reference TestFixed_Dataset layout)')
     ap.add_argument('--pairs-file', default='test_0412.txt')
     ap.add_argument('--tokenizer', default=None, help='local CLIP tokenizer directory (vocab.json + merges.txt): prompts then go through the text encoder')
+    ap.add_argument('--seed', type=int, default=None, help='start noise x_T drawn per PAIR from seed + pair index (results independent of '
+                    'batch size / sharding); default: torch.randn like the reference')
     ap.add_argument('--txt-emb', default=None, help='.pt/.safetensors with a [1,77,768] tensor: the CLIP embedding of the prompt (offline stand-in)')
     args = ap.parse_args()
 
@@ -92,7 +94,12 @@ def main():
             batch = synthetic_batch(b0, b1, args.res, model.net_config.context_dim)
             if use_clip:
                 del batch['txt_emb']          # 'txt' -> tokenizer -> mkd_clip_encode
-        out = model.test_step(batch, b0)
+        x_T = None
+        if args.seed is not None:
+            h8 = args.res // 8
+            x_T = torch.cat([torch.randn(1, model.channels, h8, h8, generator=torch.Generator().manual_seed(args.seed + i))
+                             for i in range(b0, b1)]).cuda(local)
+        out = model.test_step(batch, b0, x_T=x_T)
         model.on_test_batch_end(out, batch, b0)
         torch.save({k: v for k, v in out.items() if isinstance(v, torch.Tensor)},
                    os.path.join(args.out, f'latents_{b0:04d}.pt'))

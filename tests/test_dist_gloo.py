@@ -62,3 +62,49 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     # equals the unsharded run, in global order; fp32 torch-CPU kernels round differently per batch size (measured
     # 3.7e-6 abs on values up to 6.6), hence the tolerance
     assert np.allclose(a, one, rtol=1e-4, atol=1e-4)
+
+
+def test_spawn_ranks_self_launch_rendezvous_and_single_json_line(tmp_path):
+    """The launcher bench.py uses for a plain `python bench.py --gpus N` (no torchrun): N fresh children, env-based rendezvous on
+    127.0.0.1, rank 0's stdout is the only stdout, the exit code is the worst child's."""
+    import subprocess
+    import sys
+    child = tmp_path / 'child.py'
+    child.write_text(
+        'import json, os, sys\n'
+        f'sys.path.insert(0, {ROOT!r})\n'
+        'import torch\n'
+        'from makeupdiffuse_amd import dist as mdist\n'
+        "rank, world, local = mdist.init_from_env(backend='gloo')\n"
+        'lo, hi = mdist.shard_range(5, rank, world)\n'
+        'full = mdist.gather_shards(torch.arange(lo, hi, dtype=torch.float32)[:, None], 5)\n'
+        't = mdist.max_over_ranks(float(rank))\n'
+        'mdist.barrier()\n'
+        "print(json.dumps({'rank': rank, 'ranks_seen': torch.distributed.get_world_size(), 'backend': torch.distributed.get_backend(),\n"
+        "                  'full': full[:, 0].tolist(), 'max': t, 'extra': os.environ.get('MKD_TEST_EXTRA')}), flush=True)\n"
+        "sys.exit(3 if (rank == 1 and os.environ.get('MKD_TEST_FAIL')) else 0)\n")
+    launcher = tmp_path / 'launch.py'
+    launcher.write_text(
+        'import sys\n'
+        f'sys.path.insert(0, {ROOT!r})\n'
+        'from makeupdiffuse_amd import dist as mdist\n'
+        f"sys.exit(mdist.spawn_ranks([sys.executable, {str(child)!r}], 2, {{'MKD_TEST_EXTRA': 'x'}}, timeout=300))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, str(launcher)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]        # (gloo itself prints a connection banner on stdout)
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    import json
+    out = json.loads(lines[0])
+    assert out == {'rank': 0, 'ranks_seen': 2, 'backend': 'gloo', 'full': [0.0, 1.0, 2.0, 3.0, 4.0], 'max': 1.0, 'extra': 'x'}
+    r = subprocess.run([sys.executable, str(launcher)], capture_output=True, text=True, timeout=600, env=dict(env, MKD_TEST_FAIL='1'))
+    assert r.returncode == 3
+
+
+def test_bench_self_launch_is_decided_before_any_gpu_call():
+    """bench.py must branch into the launcher before importing the engine touches a device (a process that has initialised HIP
+    must not be the parent of the ranks' rendezvous, and must never exec)."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    main = src[src.index('def main():'):]
+    assert main.index('spawn_ranks') < main.index('init_from_env') < main.index('torch.cuda.is_available()')
+    assert 'os.exec' not in src and 'execv' not in src

@@ -43,3 +43,59 @@ def test_runs_test_py_writes_png_grids_from_a_pair_folder(tmp_path, with_tokeniz
     pairs = (out / 'test_pairs_rank0.txt').read_text().splitlines()
     assert pairs == ['0000-1 non-makeup/s1.png makeup/r1.png', '0000-2 non-makeup/s2.png makeup/r2.png']
     assert g.std() > 1.0                                                       # a decoded image, not a constant
+
+
+def test_each_pair_of_a_batched_run_equals_its_own_single_pair_run(tmp_path):
+    """PNG names and std > 1 cannot see wrong conditioning, a swapped src/ref or state leaking from one batch into the
+    next.  Three pairs, fixed per-pair start noise (--seed): the latents of the run with batch size 2 (batches [0, 1] and [2],
+    i.e. two consecutive batches through one model) must equal the batch-size-1 run pair by pair, for both sampling passes."""
+    import torch
+    from PIL import Image
+    data = tmp_path / 'data'
+    os.makedirs(data / 'images' / 'non-makeup'); os.makedirs(data / 'images' / 'makeup')
+    rng = np.random.default_rng(3)
+    lines = []
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(data / 'images' / 'non-makeup' / f's{i}.png')
+        Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(data / 'images' / 'makeup' / f'r{i}.png')
+        lines.append(f'non-makeup/s{i}.png makeup/r{i}.png')
+    (data / 'test_0412.txt').write_text('\n'.join(lines) + '\n')
+    lat = {}
+    for bs in (2, 1):
+        out = tmp_path / f'out{bs}'
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'runs', 'test.py'), '--data-root', str(data), '--res', '64', '--batch-size', str(bs),
+                            '--ddim-steps', '4', '--seed', '100', '--out', str(out)], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        files = sorted(f for f in os.listdir(out) if f.startswith('latents_'))
+        assert files == (['latents_0000.pt', 'latents_0002.pt'] if bs == 2 else ['latents_0000.pt', 'latents_0001.pt', 'latents_0002.pt'])
+        lat[bs] = [torch.load(out / f, weights_only=True) for f in files]
+    keys = ('samples_latent', 'samples_cfg_scale_9.00_latent')
+    two = {k: torch.cat([d[k] for d in lat[2]]) for k in keys}
+    one = {k: torch.cat([d[k] for d in lat[1]]) for k in keys}
+    for k in keys:
+        assert two[k].shape == one[k].shape == (3, 4, 8, 8)
+        for i in range(3):
+            r_ = float((two[k][i] - one[k][i]).norm() / one[k][i].norm())
+            print(f'{k} pair {i}: batched vs single rel-L2 {r_:.3e}')
+            assert r_ <= 3e-2, (k, i, r_)
+        # and the pairs really differ from each other (conditioning is per pair)
+        assert float((one[k][0] - one[k][1]).norm() / one[k][1].norm()) > 0.1
+    # the second batch of the batched run ([2]) is the same single pair as latents_0002 of the other run: same batch shape -> bit-exact
+    for k in keys:
+        assert torch.equal(lat[2][1][k], lat[1][2][k]), k
+
+
+def test_bench_self_launches_two_ranks_on_one_card_in_rehearsal_mode():
+    """`python bench.py --gpus 2` with no torchrun and ONE visible device: bench.py starts its own two ranks (fresh processes,
+    gloo, both on card 0), runs the sharded path with the final all-gather and rank 0 prints one JSON line that says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--ddim-steps', '2',
+                        '--batch', '2', '--no-cpu-baseline'], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == 'gloo' and out['rehearsal_single_device'] is True
+    assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['roofline']['frac'] > 0 and len(out['devices']) == 1

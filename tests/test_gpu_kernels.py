@@ -367,3 +367,29 @@ def test_ddim_step_matches_reference_formula():
     sync()
     r0 = (x - s1m * ec) / math.sqrt(a_t)
     assert torch.allclose(xp, math.sqrt(a_prev) * r0 + math.sqrt(1 - a_prev) * ec, rtol=2e-6, atol=1e-5)
+
+
+def test_patch_entry_on_a_geometry_it_does_not_fit_falls_back_with_a_big_enough_workspace():
+    """the tuned table is keyed on (M, N, K) only.  A table / override entry that names an LDS-patch tile for a
+    geometry the patch kernel rejects (here W = 12: neither < 16 nor a multiple of 16) makes launch_gemm re-plan with the generic
+    tile and HEURISTIC split-K (4 here), while the workspace used to be sized from the entry's own split (1).  Plan-time and
+    launch-time decisions now come from one function and the launch checks the slab capacity."""
+    lib = L()
+    B, H, W_, Cin, Cout = 2, 8, 12, 640, 128
+    M, K = B * H * W_, 9 * Cin
+    assert lib.mkd_gemm_cfg_supported(9, M, Cout, K, 1, H, W_, Cin, H, W_, 1, 0) == 0
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    xn = xb.permute(0, 2, 3, 1).contiguous()
+    wp = torch.empty(Cout, K, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(wbf.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    ref = F.conv2d(xb.float(), wbf.float(), bias, padding=1)
+    lib.mkd_gemm_set_override(M, Cout, K, 1, 1, 0, 9, 1)          # patch 128x64, split 1
+    try:
+        out = gemm(xn, wp, bias=bias, conv=(B, H, W_, Cin, H, W_, 1, 0))
+    finally:
+        lib.mkd_gemm_set_override(0, 0, 0, 0, 0, 0, 0, 0)
+    assert_close_bf16(out.float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what='patch override on an unsupported geometry')

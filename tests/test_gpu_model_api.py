@@ -1,0 +1,232 @@
+"""-m gpu: the reference-shaped CLASSES on the device (not just MkdEngine) against the oracle-generated golden fixtures and
+the live oracle: MKDDIMSampler.reconstruct / denoising_step (reference diffmk/cddim.py:9-100), apply_model(return_all=True)
+(makeup_diffuse.py:152-170), TestDiffuseModel.log_results' two passes (diffusion_makeup.py:391-410: plain 50 steps, then CFG 9
+with uc_cat = c_cat), generate_image / decode_latent_code (makeup_diffuse.py:172-177, makeups.py:119-127,260-262), and the
+50-step trajectories the harness really runs.  Tolerances: SURVEY.md §8c (bf16 compute vs fp32 oracle): one eps evaluation
+rel-L2 <= 2e-2 / cosine >= 0.9995; multi-step latents cosine >= 0.99.  The measured numbers are printed (-s shows them)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from makeupdiffuse_amd.diffmk.cddim import MKDDIMSampler
+from makeupdiffuse_amd.diffmk.makeup_diffuse import TestDiffuseModel
+from oracle import nets, sampler, vae
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+NET = dict(in_channels=4, model_channels=64, channel_mult=[1, 2], attention_resolutions=[1, 2], num_res_blocks=2, num_heads=2,
+           context_dim=64, use_spatial_transformer=True, transformer_depth=1, legacy=False)
+HINT_WIDTHS = [16, 16, 32, 32, 32, 32, 64]
+VSMALL = dict(z_channels=4, ch=32, ch_mult=[1, 2], num_res_blocks=1, out_ch=3, attn_resolutions=[])
+
+
+def metrics(out, ref):
+    out = out.float().cpu(); ref = ref.float().cpu()
+    assert torch.isfinite(out).all(), 'non-finite output'
+    return ((out - ref).norm() / ref.norm()).item(), F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+
+
+def check(out, ref, rel, cos, what):
+    r, c = metrics(out, ref)
+    print(f'[parity] {what}: rel-L2 {r:.4e} cos {c:.6f} (limits {rel:g} / {cos:g})')
+    assert r <= rel and c >= cos, f'{what}: rel-L2 {r:.4e} (<= {rel}), cos {c:.6f} (>= {cos})'
+    return r, c
+
+
+def build_model(hint_channels=6, cls=TestDiffuseModel, **kw):
+    ctrl = dict(NET, hint_channels=hint_channels, hint_widths=HINT_WIDTHS)
+    unet = dict(NET, out_channels=4)
+    return cls(control_stage_config={'params': ctrl}, unet_config={'params': unet},
+               first_stage_config={'params': {'embed_dim': 4, 'ddconfig': dict(VSMALL)}}, ddim_steps=50, ddim_eta=0.0,
+               unconditional_guidance_scale=9, **kw)
+
+
+@pytest.fixture(scope='module')
+def G():
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    return {k: torch.from_numpy(np.asarray(g[k])) for k in g.files}
+
+
+@pytest.fixture(scope='module')
+def weights(G):
+    ocfg = nets.NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+                          hint_widths=tuple(HINT_WIDTHS))
+    sd = nets.init_state_dict(ocfg, seed=int(G['seed_weights']))
+    vcfg = vae.VaeConfig(z_channels=4, embed_dim=4, ch=32, ch_mult=(1, 2), num_res_blocks=1, out_ch=3)
+    vsd = vae.init_state_dict(vcfg, seed=int(G['seed_vae']))
+    return ocfg, sd, vcfg, vsd
+
+
+@pytest.fixture(scope='module')
+def model(G, weights):
+    ocfg, sd, vcfg, vsd = weights
+    m = build_model()
+    m.load_state_dict({**sd, **vsd})
+    m.cuda(0)
+    m.uncond_embedding = G['uctx']                     # stands for CLIP("") (diffusion_makeup.py:400); same rows as the fixture
+    m.save_images = False
+    return m
+
+
+def cond_of(G, dev='cuda:0'):
+    return {'c_crossattn': [G['ctx'].to(dev)], 'c_concat': [G['hint'].to(dev)]}
+
+
+def test_apply_model_return_all_vs_golden(model, G):
+    c = cond_of(G)
+    x, t = G['x'].cuda(), G['t'].cuda()
+    eps, x_recon = model.apply_model(x, t, c, return_all=True)
+    check(eps, G['eps'], 2e-2, 0.9995, 'apply_model eps')
+    check(x_recon, G['x_recon'], 2e-2, 0.9995, 'apply_model x_recon (predict_start_from_noise)')
+    assert torch.equal(model.apply_model(x, t, c), eps)
+    model.only_mid_control = True                      # runs/test.py:63 sets the attribute on the model
+    check(model.apply_model(x, t, c), G['eps_mid'], 2e-2, 0.9995, 'only_mid_control attribute')
+    model.only_mid_control = False
+    model.control_scales = [float(s) for s in G['scales']]
+    check(model.apply_model(x, t, c), G['eps_scaled'], 2e-2, 0.9995, 'control_scales attribute')
+    model.control_scales = [1.0] * len(G['scales'])
+    check(model.apply_model(x, t, {'c_crossattn': c['c_crossattn'], 'c_concat': None}), G['eps_noctl'], 2e-2, 0.9995, 'c_concat None')
+
+
+def test_mkddim_sampler_on_device_vs_golden(model, G):
+    """reconstruct(t_start < S) through the in-library loop AND through the step-by-step path (callback given), one
+    denoising_step with and without CFG: reference diffmk/cddim.py:9-100."""
+    s = MKDDIMSampler(model)
+    s.make_schedule(ddim_num_steps=10, verbose=False)
+    c = cond_of(G)
+    uc = {'c_crossattn': [G['uctx'].cuda()], 'c_concat': c['c_concat']}
+    x = G['x'].cuda()
+    fast = s.reconstruct(x, c, t_start=4)
+    check(fast, G['rec4'], 6e-2, 0.99, 'reconstruct(t_start=4), mkd_sample path')
+    seen = []
+    slow = s.reconstruct(x, c, t_start=4, callback=seen.append)
+    assert seen == [0, 1, 2, 3]
+    check(slow, G['rec4'], 6e-2, 0.99, 'reconstruct(t_start=4), step-by-step path')
+    check(slow, fast, 1e-5, 0.999999, 'step-by-step == in-library loop')
+    fastc = s.reconstruct(x, c, t_start=4, unconditional_guidance_scale=9.0, unconditional_conditioning=uc)
+    check(fastc, G['rec4_cfg'], 6e-2, 0.99, 'reconstruct(t_start=4, CFG 9)')
+    slowc = s.reconstruct(x, c, t_start=4, unconditional_guidance_scale=9.0, unconditional_conditioning=uc, callback=lambda i: None)
+    check(slowc, fastc, 1e-5, 0.999999, 'CFG: step-by-step == in-library loop')
+    ts = torch.full((x.shape[0],), int(s.ddim_timesteps[6]), device='cuda:0', dtype=torch.long)
+    xp, x0 = s.denoising_step(x, c, ts, index=6)
+    check(xp, G['step_prev'], 2e-2, 0.9995, 'denoising_step x_prev')
+    check(x0, G['step_x0'], 2e-2, 0.9995, 'denoising_step pred_x0')
+    xp, x0 = s.denoising_step(x, c, ts, index=6, unconditional_guidance_scale=9.0, unconditional_conditioning=uc)
+    check(xp, G['stepc_prev'], 5e-2, 0.999, 'denoising_step CFG 9 x_prev')
+    check(x0, G['stepc_x0'], 5e-2, 0.999, 'denoising_step CFG 9 pred_x0')
+    with pytest.raises(NotImplementedError):
+        s.denoising_step(x, c, ts, index=6, dynamic_threshold=0.5)              # cddim.py:70-71
+
+
+def test_log_results_two_passes_vs_golden(model, G):
+    """What runs/test.py runs per batch (diffusion_makeup.py:391-410): 50 DDIM steps plain, then CFG 9 with the SAME hint in the
+    unconditional branch; latents and decoded images against the oracle's sample() x 2 and decode_first_stage."""
+    batch = {'src_img': G['hint'][:, :3], 'ref_img': G['hint'][:, 3:], 'txt_emb': G['ctx'], 'img_name': ['a&b', 'c&d']}
+    log = model.log_results(batch, 0, x_T=G['x'].cuda())
+    check(log['samples_latent'], G['x50'], 6e-2, 0.99, '50-step latent (samples)')
+    check(log['samples_cfg_scale_9.00_latent'], G['x50_cfg'], 0.1, 0.99, '50-step CFG-9 latent (samples_cfg_scale_9.00)')
+    check(log['samples'], G['img50'], 8e-2, 0.99, '50-step decoded image')
+    assert torch.equal(log['control_src'].cpu(), G['hint'][:, :3] * 2 - 1) and torch.equal(log['control_ref'].cpu(), G['hint'][:, 3:] * 2 - 1)
+    assert model.test_pairs[-2:] == [['0000-1', 'non-makeup/a.png', 'makeup/b.png'], ['0000-2', 'non-makeup/c.png', 'makeup/d.png']]
+
+
+def test_generate_image_and_decode_latent_code(model, G, weights):
+    ocfg, sd, vcfg, vsd = weights
+    z = G['x50'].cuda()
+    raw = model.decode_latent_code(z)
+    check(raw, G['img50'], 2e-2, 0.9995, 'decode_latent_code')
+    img = model.generate_image(z)
+    assert float(img.min()) >= -1.0 and float(img.max()) <= 1.0
+    check(img, G['img50'].clamp(-1, 1), 2e-2, 0.9995, 'generate_image(format=False)')
+    img01 = model.generate_image(z, format=True)
+    assert float(img01.min()) >= 0.0 and float(img01.max()) <= 1.0
+    check(img01, (G['img50'].clamp(-1, 1) + 1) / 2, 2e-2, 0.9995, 'generate_image(format=True)')
+
+
+def test_makeups_generate_image_caller_shape(G):
+    """reference diffmk/makeups.py:119-127: reconstruct(x_latent=inv, cond=c, t_start=iter_finetune) -> decode_latent_code ->
+    (x + 1) / 2 clamped; the hint of that variant is ONE image (3 channels).  Oracle evaluated live."""
+    from makeupdiffuse_amd.diffmk.makeups import BaseModel
+    ocfg = nets.NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+                          hint_channels=3, hint_widths=tuple(HINT_WIDTHS))
+    sd = nets.init_state_dict(ocfg, seed=21)
+    vcfg = vae.VaeConfig(z_channels=4, embed_dim=4, ch=32, ch_mult=(1, 2), num_res_blocks=1, out_ch=3)
+    vsd = vae.init_state_dict(vcfg, seed=22)
+    m = build_model(hint_channels=3, cls=BaseModel, iter_finetune=6)
+    m.load_state_dict({**sd, **vsd})
+    m.cuda(0)
+    m.on_fit_start()
+    src, ref = G['hint'][:, :3], G['hint'][:, 3:]
+    inv = G['x']
+    c = dict(c_crossattn=[G['ctx'].cuda()], c_concat_s=[src.cuda()], c_concat_r=[ref.cuda()])
+    got = m.generate_image(inv.cuda(), c, c_type='c_concat_r')
+    assert c['c_concat'] is c['c_concat_r']                                    # the reference mutates the cond dict the same way
+    sch = sampler.Schedule().make_ddim(6)
+    z = sampler.reconstruct(sampler.make_eps_fn(sd, ocfg), sch, inv, {'c_crossattn': [G['ctx']], 'c_concat': [ref]}, 6)
+    want = ((vae.decode_first_stage(vsd, vcfg, z) + 1.0) / 2.0).clamp(0, 1)
+    check(got, want, 5e-2, 0.995, 'makeups.generate_image (6-step reconstruct + decode + [0,1])')
+    got2 = m.generate_image(inv.cuda(), c, c_replace=[src.cuda()])
+    z2 = sampler.reconstruct(sampler.make_eps_fn(sd, ocfg), sch, inv, {'c_crossattn': [G['ctx']], 'c_concat': [src]}, 6)
+    check(got2, ((vae.decode_first_stage(vsd, vcfg, z2) + 1.0) / 2.0).clamp(0, 1), 5e-2, 0.995, 'makeups.generate_image(c_replace)')
+    m.engine.close()
+
+
+def test_back_to_back_batches_do_not_reuse_conditioning(model, G, weights):
+    """Two DIFFERENT batches of identical shape through the harness loop, freeing the first before building the second (the
+    caching allocator then hands out the same addresses): batch 2's result must equal a fresh model's result for batch 2.  An
+    address-keyed conditioning cache returns batch 1's hint embedding / K-V caches here."""
+    ocfg, sd, vcfg, vsd = weights
+    gen = torch.Generator().manual_seed(77)
+
+    def make_batch():
+        return {'src_img': torch.rand(2, 3, 64, 64, generator=gen), 'ref_img': torch.rand(2, 3, 64, 64, generator=gen),
+                'txt_emb': torch.randn(2, 77, 64, generator=gen)}
+    b1, b2 = make_batch(), make_batch()
+    model.ddim_steps = 5
+    xT = G['x'].cuda()
+    try:
+        for with_cfg, plain in ((9, True), (9, False), (1.0, True)):
+            model.unconditional_guidance_scale, model.sample = with_cfg, plain
+            out1 = model.log_results({k: v.clone() for k, v in b1.items()}, 0, x_T=xT)
+            del out1                                             # freed blocks stay cached: the next batch gets the same addresses
+            out2 = model.log_results({k: v.clone() for k, v in b2.items()}, 1, x_T=xT)
+            fresh = build_model()
+            fresh.load_state_dict({**sd, **vsd}); fresh.cuda(0)
+            fresh.uncond_embedding = G['uctx']; fresh.ddim_steps = 5
+            fresh.unconditional_guidance_scale, fresh.sample = with_cfg, plain
+            want = fresh.log_results({k: v.clone() for k, v in b2.items()}, 1, x_T=xT)
+            for k in want:
+                if k.endswith('_latent'):
+                    assert torch.equal(out2[k], want[k]), f'{k} (cfg {with_cfg}, plain pass {plain}): batch 2 differs from a fresh model'
+            fresh.engine.close()
+        # the step-by-step path (eta > 0 / callback) binds through apply_model: same requirement
+        s = MKDDIMSampler(model); s.make_schedule(ddim_num_steps=5, verbose=False)
+        outs = []
+        for b in (b1, b2):
+            _, c = model.get_input({k: v.clone() for k, v in b.items()}, 'jpg')
+            outs.append(s.reconstruct(xT, {'c_crossattn': c['c_crossattn'], 'c_concat': c['c_concat']}, t_start=2, callback=lambda i: None))
+            del c
+        _, c2 = model.get_input(b2, 'jpg')
+        model.reset_conditioning_cache()
+        again = s.reconstruct(xT, {'c_crossattn': c2['c_crossattn'], 'c_concat': c2['c_concat']}, t_start=2, callback=lambda i: None)
+        assert torch.equal(outs[1], again) and not torch.equal(outs[0], outs[1])
+    finally:
+        model.ddim_steps, model.unconditional_guidance_scale, model.sample = 50, 9, True
+
+
+def test_sample_rejects_a_latent_that_does_not_match_the_prepared_hint(model, G):
+    eng = model.engine
+    eng.prepare(G['hint'], G['ctx'])
+    sch = sampler.Schedule().make_ddim(3)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    with pytest.raises(ValueError):
+        eng.sample(torch.randn(2, 4, 4, 4), *args)             # smaller H, W than the hint implies
+    with pytest.raises(ValueError):
+        eng.sample(torch.randn(2, 3, 8, 8), *args)             # wrong channel count
+    with pytest.raises(ValueError):
+        eng.sample(torch.randn(1, 4, 8, 8), *args)             # wrong batch
+    with pytest.raises(ValueError):
+        eng.sample(torch.randn(2, 4, 8, 8), *args, cfg_scale=9.0)     # CFG needs a 2B prepared batch

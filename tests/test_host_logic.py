@@ -177,6 +177,109 @@ def test_ddim_sampler_full_loop_from_x_T(gold):
     assert len(inter['x_inter']) >= 2
 
 
+# ---- model-class host logic with a recording stand-in engine (no GPU) ---------------------------------------------------
+class _RecordingEngine:
+    """Stands for MkdEngine on the CPU: records prepare() calls, answers eps/decode with tagged tensors."""
+    vae_cfg = object()
+
+    def __init__(self):
+        self.prepared = []
+
+    def prepare(self, hint, ctx, **kw):
+        self.prepared.append((None if hint is None else float(hint.sum()), float(ctx.sum())))
+
+    def eps(self, x, t):
+        return torch.full_like(x, self.prepared[-1][1])
+
+    def decode(self, z, scale_factor):
+        return z[:, :3] * 4.0 / scale_factor * 0.18215
+
+
+def test_conditioning_cache_is_keyed_on_the_tensor_objects_not_their_addresses():
+    """ADVICE r1 (high): a (data_ptr, version, shape) key matches a NEW tensor that the allocator placed where a freed one was;
+    the cache must hold the tensors and compare identity + version."""
+    from makeupdiffuse_amd.diffmk.makeup_diffuse import BaseMakeUpDiffuse, _Held
+    m = create_model(os.path.join(ROOT, 'diffmodels', 'test_diffusion_makeup.yaml'))
+    eng = _RecordingEngine()
+    m._require_engine = lambda: eng
+    x, t = torch.zeros(1, 4, 8, 8), torch.zeros(1, dtype=torch.long)
+
+    def cond(v):
+        return {'c_crossattn': [torch.full((1, 77, 768), float(v))], 'c_concat': [torch.full((1, 6, 64, 64), float(v))]}
+    c1 = cond(1)
+    m.apply_model(x, t, c1); m.apply_model(x, t, c1)
+    assert len(eng.prepared) == 1                                  # same objects, unchanged: bound once
+    c1['c_crossattn'][0].add_(1.0)                                  # in-place edit bumps ._version
+    m.apply_model(x, t, c1)
+    assert len(eng.prepared) == 2
+    # a different tensor of the same shape re-binds even when it sits at the SAME address (storage shared on purpose here)
+    alias = {'c_crossattn': [c1['c_crossattn'][0].view(1, 77, 768)], 'c_concat': [c1['c_concat'][0].view(1, 6, 64, 64)]}
+    assert alias['c_concat'][0].data_ptr() == c1['c_concat'][0].data_ptr() and alias['c_concat'][0] is not c1['c_concat'][0]
+    out = m.apply_model(x, t, alias)
+    assert len(eng.prepared) == 3 and float(out[0, 0, 0, 0]) == eng.prepared[-1][1]
+    # the held tensors cannot be freed (hence their addresses cannot be recycled) while the entry is live
+    import weakref
+    c2 = cond(5)
+    ref = weakref.ref(c2['c_concat'][0])
+    m.apply_model(x, t, c2)
+    del c2
+    assert ref() is not None
+    m.reset_conditioning_cache()
+    assert ref() is None
+    # CFG merge cache: same rule
+    u, c = cond(0), cond(3)
+    a = m.cfg_conditioning(u, c); b = m.cfg_conditioning(u, c)
+    assert a is b and a['c_concat'][0].shape[0] == 2 and float(a['c_crossattn'][0][0].sum()) == 0.0     # uncond first
+    c_new = cond(4)
+    assert m.cfg_conditioning(u, c_new) is not a
+    h = _Held((u['c_concat'][0], None), ('k',))
+    assert h.matches((u['c_concat'][0], None), ('k',)) and not h.matches((u['c_concat'][0], None), ('j',))
+    assert not h.matches((u['c_concat'][0].clone(), None), ('k',))
+
+
+def test_generate_image_and_decode_latent_code_follow_the_reference():
+    """makeup_diffuse.py:172-177 (decode -> clamp(-1, 1) -> optional (x + 1) / 2) and makeups.py:260-262 (unclamped decode)."""
+    m = create_model(os.path.join(ROOT, 'diffmodels', 'test_diffusion_makeup.yaml'))
+    eng = _RecordingEngine()
+    m._require_engine = lambda: eng
+    z = torch.linspace(-1, 1, 2 * 4 * 2 * 2).reshape(2, 4, 2, 2)
+    raw = m.decode_latent_code(z)
+    assert torch.equal(raw, m.decode_first_stage(z)) and float(raw.abs().max()) > 1.0
+    a = m.generate_image(z)
+    assert torch.equal(a, raw.clamp(-1, 1))
+    b = m.generate_image(z, format=True)
+    assert torch.equal(b, (raw.clamp(-1, 1) + 1.0) / 2.0) and float(b.min()) >= 0.0 and float(b.max()) <= 1.0
+
+
+def test_makeups_generate_image_call_shape_with_oracle_backed_model(gold):
+    """reference diffmk/makeups.py:44-47,119-127 on the CPU with the oracle as eps model / decoder: reconstruct(x_latent=inv,
+    cond=c, t_start=iter_finetune) -> decode_latent_code -> (x + 1) / 2 clamped to [0, 1]; c['c_concat'] chosen by c_type."""
+    from diffmk.makeups import BaseModel
+    from oracle import vae
+    torch.set_num_threads(4)
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=11)
+    vcfg = vae.VaeConfig(z_channels=4, embed_dim=4, ch=32, ch_mult=(1, 2), num_res_blocks=1, out_ch=3)
+    vsd = vae.init_state_dict(vcfg, seed=5)
+    ctrl = dict(SMALL, hint_channels=6, num_res_blocks=2, in_channels=4, use_spatial_transformer=True, legacy=False)
+    m = BaseModel(control_stage_config={'params': ctrl}, unet_config={'params': dict(ctrl, out_channels=4)}, iter_finetune=5)
+    m.apply_model = lambda x, t, c, *a, **k: sampler.apply_model(sd, ocfg, x, t, c)     # stand-ins for the device engine
+    m.decode_first_stage = lambda z: vae.decode_first_stage(vsd, vcfg, z)
+    m.sample_loop_fast = None
+    m.ddim_step = None
+    m.on_fit_start()
+    assert m.ddim_sampler.ddim_timesteps.shape[0] == 5
+    c = dict(c_crossattn=[gold['ctx']], c_concat_r=[gold['hint']], c_concat_s=[gold['hint'].flip(1)])
+    img = m.generate_image(gold['x'], c, c_type='c_concat_r')
+    assert c['c_concat'] is c['c_concat_r']
+    want = ((vae.decode_first_stage(vsd, vcfg, gold['x5']) + 1.0) / 2.0).clamp(0, 1)
+    assert torch.allclose(img, want, rtol=1e-4, atol=1e-5) and float(img.min()) >= 0 and float(img.max()) <= 1
+    img2 = m.generate_image(gold['x'], c, c_replace=c['c_concat_s'])
+    assert c['c_concat'] is c['c_concat_s'] and not torch.allclose(img2, img)
+    with pytest.raises(NotImplementedError):
+        m.shared_step({})
+
+
 # ---- batch sharding ------------------------------------------------------------------------------------------------
 def test_shard_range_partitions_exactly():
     for n in (1, 7, 8, 64, 352):

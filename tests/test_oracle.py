@@ -129,3 +129,36 @@ def test_cfg_batches_uncond_first():
     c = {'c_crossattn': [torch.ones(1, 2, 3)], 'c_concat': [torch.ones(1, 1)]}
     m = sampler.cat_cond(u, c)
     assert m['c_crossattn'][0][0].sum() == 0 and m['c_crossattn'][0][1].sum() == 6     # cddim.py:25-31
+
+
+def test_fixture_weights_expose_a_miswired_norm_parameter(small):
+    """with gamma = 1 / beta = 0 everywhere a swapped norm1/norm2/norm3 or in_layers.0/out_layers.0, or a dropped
+    beta, is invisible to every golden file.  The fixture initialiser draws them at random; each such mistake must now move
+    the golden eps far outside the GPU tests' 2e-2 budget."""
+    cfg, sd, g = small
+    cond = {'c_crossattn': [g['ctx']], 'c_concat': [g['hint']]}
+    norms = [k for k in sd if k.endswith('.weight') and sd[k].dim() == 1 and ('norm' in k or 'in_layers.0' in k or 'out_layers.0' in k or k.endswith('out.0.weight'))]
+    assert len(norms) > 40 and all(float((sd[k] - 1).abs().max()) > 0.05 for k in norms)
+    assert all(float(sd[k[:-6] + 'bias'].abs().max()) > 0.05 for k in norms)
+
+    def rel_after(edit):
+        sd2 = dict(sd)
+        edit(sd2)
+        out = sampler.apply_model(sd2, cfg, g['x'], g['t'], cond)
+        return float((out - g['eps']).norm() / g['eps'].norm())
+
+    def swap(a, b):
+        def f(d):
+            for s in ('.weight', '.bias'):
+                d[a + s], d[b + s] = d[b + s], d[a + s]
+        return f
+    T = 'model.diffusion_model.input_blocks.1.1.transformer_blocks.0'
+    R = 'model.diffusion_model.output_blocks.4.0'
+    assert rel_after(swap(T + '.norm1', T + '.norm2')) > 0.05
+    assert rel_after(swap(T + '.norm2', T + '.norm3')) > 0.05
+    assert sd[R + '.in_layers.0.weight'].shape != sd[R + '.out_layers.0.weight'].shape        # (concat input): swap a same-width pair instead
+    R2 = 'control_model.input_blocks.2.0'
+    assert rel_after(swap(R2 + '.in_layers.0', R2 + '.out_layers.0')) > 0.05
+    def drop_beta(d):
+        d[R + '.out_layers.0.bias'] = torch.zeros_like(d[R + '.out_layers.0.bias'])
+    assert rel_after(drop_beta) > 0.02
