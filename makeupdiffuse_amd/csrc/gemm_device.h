@@ -27,6 +27,73 @@ struct Epilogue {
     int ldrb; int rpb; int ldr; int ldc; float scale; int act; int out_f32; int pad_;
 };
 
+// ---- GroupNorm statistics emitted by the PRODUCER of a tensor ---------------------------------------------------------
+// A GroupNorm needs (sum, sum of squares) over all pixels and the group's channels of one sample: a full pass over a tensor
+// that the kernel writing it already holds in registers.  Producers therefore add their share into gstat[sample][group][2],
+// 64-bit FIXED-POINT integers (sum * 2^24, sumsq * 2^18): integer addition is associative, so the totals are bit-identical
+// whatever order the workgroups (and the device-scope atomics) arrive in - float atomics would make every GroupNorm, and
+// with it every evaluation, run-to-run different.  The absolute quantisation error of a partial is 2^-25 (sum) / 2^-19
+// (sumsq) per >= 16 values, far below the GroupNorm eps (1e-5 / 1e-6); the range is |x| < ~1e4 for 2^17 values per group.
+constexpr float GN_FIX_SUM = 16777216.0f;      // 2^24
+constexpr float GN_FIX_SQ = 262144.0f;         // 2^18
+constexpr int GN_GROUPS = 32;
+
+__device__ __forceinline__ void gn_atomic_add(long long* p, long long v) {
+    atomicAdd((unsigned long long*)p, (unsigned long long)v);       // two's complement: wraps correctly for negative sums
+}
+
+// Column statistics of one output tile that the workgroup has staged in LDS as bf16 [rows][TS] (exactly the values it
+// stored to memory).  Thread (chunk, c) walks its rows of column c in order; rows are grouped into SEGMENTS of seg_period
+// consecutive rows (segment s of the tile = sample b_first + s; row 0 sits at position phase0 of its segment).  Per
+// (segment, group) the per-thread partials are added in LDS (integers: order-free), then ONE global atomic per entry.
+// acc: LDS scratch for nseg * ngl pairs (acc_cap pairs available; tiny geometries that exceed it go straight to global).
+// Must be called by ALL threads of the block (barriers inside).
+__device__ __forceinline__ void gn_tile_stats(const uint16_t* tile, int TS, int TM, int TN, int nthreads, int tid,
+                                              int valid_rows, int valid_cols, int seg_period, int phase0, int b_first,
+                                              int cg, int cfirst, long long* acc, int acc_cap, long long* gstat) {
+    const int nseg = (phase0 + valid_rows - 1) / seg_period + 1;
+    const int g_first = cfirst / cg;
+    const int ngl = (cfirst + valid_cols - 1) / cg - g_first + 1;
+    const bool use_lds = nseg * ngl <= acc_cap;
+    if (use_lds)
+        for (int i = tid; i < nseg * ngl * 2; i += nthreads) acc[i] = 0;
+    __syncthreads();                                   // tile written, acc zeroed
+    const int R = nthreads / TN;                       // row chunks (TN <= 160 < 256 threads)
+    const int rows_per = (TM + R - 1) / R;
+    const int c = tid % TN, chunk = tid / TN;
+    if (chunk < R && c < valid_cols) {
+        const int lr0 = chunk * rows_per;
+        const int lr1 = min(valid_rows, lr0 + rows_per);
+        if (lr0 < lr1) {
+            const int gl = (cfirst + c) / cg - g_first;
+            int seg = (phase0 + lr0) / seg_period;
+            int left = seg_period - (phase0 + lr0 - seg * seg_period);
+            float sm = 0.f, sq = 0.f;
+            auto flush = [&]() {
+                const long long a = __float2ll_rn(sm * GN_FIX_SUM), q = __float2ll_rn(sq * GN_FIX_SQ);
+                long long* dst = use_lds ? acc + (size_t)(seg * ngl + gl) * 2 : gstat + ((size_t)(b_first + seg) * GN_GROUPS + g_first + gl) * 2;
+                if (a) gn_atomic_add(dst, a);
+                if (q) gn_atomic_add(dst + 1, q);
+            };
+            for (int lr = lr0; lr < lr1; ++lr) {
+                const float v = bf16_to_f32(tile[lr * TS + c]);
+                sm += v; sq += v * v;
+                if (--left == 0) { flush(); sm = 0.f; sq = 0.f; ++seg; left = seg_period; }
+            }
+            if (left != seg_period) flush();
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = tid; i < nseg * ngl; i += nthreads) {
+            const long long a = acc[i * 2], q = acc[i * 2 + 1];
+            long long* dst = gstat + ((size_t)(b_first + i / ngl) * GN_GROUPS + g_first + i % ngl) * 2;
+            if (a) gn_atomic_add(dst, a);
+            if (q) gn_atomic_add(dst + 1, q);
+        }
+    }
+}
+
 __device__ __forceinline__ Epilogue make_epilogue(const GemmArgs& p) {
     Epilogue e;
     e.bias = p.bias; e.rowbias = p.rowbias; e.R = p.R; e.C = p.C; e.ln_s = p.ln_s;
@@ -98,6 +165,15 @@ __device__ __forceinline__ f32x4 epilogue_write(const Epilogue& e, int m, int n,
     for (int j = 0; j < 4; ++j) { o.v[j] = f32_to_bf16(v[j]); r[j] = bf16_to_f32(o.v[j]); }
     *(U16x4*)((bf16_t*)e.C + (size_t)m * e.ldc + n) = o;
     return r;
+}
+
+// bf16 store that also hands back the stored bits (GroupNorm statistics are taken of exactly what the consumer will read)
+__device__ __forceinline__ U16x4 epilogue_write_bits(const Epilogue& e, int m, int n, f32x4 v) {
+    U16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = f32_to_bf16(v[j]);
+    *(U16x4*)((bf16_t*)e.C + (size_t)m * e.ldc + n) = o;
+    return o;
 }
 
 __device__ __forceinline__ void epilogue_store(const Epilogue e, int m, int n, f32x4 v) {

@@ -213,6 +213,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------
+    // GroupNorm statistics of the output (gemm_device.h): tile row = local pixel index of the spatial tile (image-major), one
+    // segment per image of the tile
+    long long* const gn_stat = p.gn_stat;
+    constexpr int GTS = TN + 4;
+    constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
+    constexpr int LDS_MIN = 2 * 4 * NW * 1024 + STAGES * WSB;            // smallest patch slot (PP >= 4)
+    static_assert(GTILE + 64 * 16 <= LDS_MIN, "GroupNorm statistics tile must fit in the staging buffers");
+    uint16_t* const gtile = (uint16_t*)smem;
+    const bool gns = gn_stat != nullptr && splitk == 1;
+    if (gns) __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mrow[mi];
@@ -222,9 +232,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
             const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
             if (n >= N) continue;
             if (splitk > 1) *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
-            else epilogue_write(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
+            else {
+                const f32x4 val = epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]);
+                if (gns) {
+                    const U16x4 o = epilogue_write_bits(epi, m, n, val);
+                    *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
+                } else {
+                    epilogue_write(epi, m, n, val);
+                }
+            }
         }
     }
+    if (gns)
+        gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, (batch - b0) * TH * TW), min(TN, N - n0), TH * TW, 0, b0, p.gn_cg,
+                      p.gn_coff + n0, (long long*)(smem + GTILE), (LDS_MIN - GTILE) / 16, gn_stat);
 }
 
 template <int TM, int TN, int WM, int WN, int PP>

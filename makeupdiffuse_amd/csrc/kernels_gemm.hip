@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 
     const float* const stat_in = p.stat_in; const int stat_in_slots = p.stat_in_slots;
     float* const stat_out = p.stat_out;
+    long long* const gn_stat = p.gn_stat; const int gn_cg = p.gn_cg, gn_coff = p.gn_coff, gn_hw = p.gn_hw;
     constexpr int SL = LN > 0 ? LN : 1;          // LN = 0: off; 1 / 3 / 5: stat loads per lane per row
     float2 lnt[LN ? MI : 1][SL];
 
@@ -243,6 +244,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
     float* const statlds = (float*)(smem + STAGES * STAGE);        // [WN][TM][2] scratch behind the ring
+    // GroupNorm statistics of the output (gemm_device.h): the stored bf16 tile is also staged in LDS (the ring is free once
+    // every wave has left the K loop) and reduced per (sample, group) by gn_tile_stats.
+    constexpr int GTS = TN + 4;                                    // tile row stride in elements (8-byte aligned rows)
+    constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
+    constexpr int LDS_TOTAL = STAGES * STAGE + WN * TM * 2 * 4;
+    static_assert(GTILE + 64 * 16 <= LDS_TOTAL, "GroupNorm statistics tile must fit in the ring");
+    uint16_t* const gtile = (uint16_t*)smem;
+    const bool gns = gn_stat != nullptr && splitk == 1;            // (block-uniform)
+    if (gns) __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
@@ -259,9 +269,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
                     *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
                 } else {
                     const f32x4 v0 = LN ? ln_correct(ln_s, n, acc[ni][mi], mu, rstd) : acc[ni][mi];
-                    const f32x4 r = epilogue_write(epi, m, n, pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0));
-                    ps += (r[0] + r[1]) + (r[2] + r[3]);
-                    pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                    const f32x4 val = pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0);
+                    if (gns) {
+                        const U16x4 o = epilogue_write_bits(epi, m, n, val);
+                        *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
+                    } else {
+                        const f32x4 r = epilogue_write(epi, m, n, val);
+                        ps += (r[0] + r[1]) + (r[2] + r[3]);
+                        pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                    }
                 }
             }
         }
@@ -272,6 +288,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
             if (fq == 0) { statlds[(wn * TM + lr) * 2] = ps; statlds[(wn * TM + lr) * 2 + 1] = pq; }
         }
     }
+    if (gns)
+        gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, M - m0), min(TN, N - n0), gn_hw, m0 % gn_hw, m0 / gn_hw, gn_cg,
+                      gn_coff + n0, (long long*)(smem + GTILE), (LDS_TOTAL - GTILE) / 16, gn_stat);
     if (stat_out && splitk == 1) {         // one slot per column tile: wave columns summed in a fixed order
         __syncthreads();
         for (int lr = tid; lr < TM; lr += 64 * NW) {
@@ -320,6 +339,85 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
         if ((threadIdx.x & 63) == 0 && m < p.M) *(float2*)(p.stat_out + ((size_t)blockIdx.x * p.M + m) * 2) = float2{ps, pq};
+    }
+}
+
+// split-K reduce + epilogue that also emits the GroupNorm statistics of its output: 16 rows x 256 columns per block, a wave
+// walks 4 consecutive rows (same 4 columns per lane), per-lane sums are flushed when the sample changes, reduced per
+// (sample, group) in LDS (integer adds: order-free) and added to gn_stat with one device-scope atomic per entry.
+__global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs p) {
+    constexpr int CAP = 512;
+    __shared__ long long acc[CAP * 2];
+    const int tid = threadIdx.x;
+    const int n = (blockIdx.x * 64 + (tid & 63)) << 2;
+    const int mb = blockIdx.y * 16;
+    const int hw = p.gn_hw, cg = p.gn_cg;
+    const int rows = min(16, p.M - mb);
+    const int b_first = mb / hw;
+    const int nseg = (mb + rows - 1) / hw - b_first + 1;
+    const int c0 = p.gn_coff + blockIdx.x * 256;                      // consumer-tensor column of this block's first column
+    const int ncol = min(256, p.N - blockIdx.x * 256);
+    const int g_first = c0 / cg;
+    const int ngl = (c0 + ncol - 1) / cg - g_first + 1;
+    const bool use_lds = nseg * ngl <= CAP;
+    if (use_lds)
+        for (int i = tid; i < nseg * ngl * 2; i += 256) acc[i] = 0;
+    __syncthreads();
+    if (n < p.N) {
+        const Epilogue e = make_epilogue(p);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (e.bias) b4 = *(const f32x4*)(e.bias + n);
+        const size_t slab = (size_t)p.M * p.N;
+        int gl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gl[j] = (p.gn_coff + n + j) / cg - g_first;
+        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        int cur = -1;
+        auto flush = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long a = __float2ll_rn(sm[j] * GN_FIX_SUM), q = __float2ll_rn(sq[j] * GN_FIX_SQ);
+                long long* dst = use_lds ? acc + (size_t)((cur - b_first) * ngl + gl[j]) * 2
+                                         : p.gn_stat + ((size_t)cur * GN_GROUPS + g_first + gl[j]) * 2;
+                if (a) gn_atomic_add(dst, a);
+                if (q) gn_atomic_add(dst + 1, q);
+                sm[j] = 0.f; sq[j] = 0.f;
+            }
+        };
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + (tid >> 6) * 4 + i;
+            if (m >= p.M) break;
+            U16x4 r4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r4.v[j] = 0;
+            if (e.R) r4 = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
+            const float* src = p.ws + (size_t)m * p.N + n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int z = 0;
+            for (; z + 4 <= p.splitk; z += 4) {
+                const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
+                const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
+                const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
+                const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
+                v += (a + b) + (c + d);
+            }
+            for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
+            const U16x4 o = epilogue_write_bits(e, m, n, epilogue_value_pre(e, m, n, v, b4, r4));
+            const int b = m / hw;
+            if (b != cur) { if (cur >= 0) flush(); cur = b; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float f = bf16_to_f32(o.v[j]); sm[j] += f; sq[j] += f * f; }
+        }
+        if (cur >= 0) flush();
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = tid; i < nseg * ngl; i += 256) {
+            const long long a = acc[i * 2], q = acc[i * 2 + 1];
+            long long* dst = p.gn_stat + ((size_t)(b_first + i / ngl) * GN_GROUPS + g_first + i % ngl) * 2;
+            if (a) gn_atomic_add(dst, a);
+            if (q) gn_atomic_add(dst + 1, q);
+        }
     }
 }
 
@@ -540,6 +638,8 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.ln_s && (!a.stat_in || a.stat_in_slots <= 0 || a.stat_in_slots > 20))
         return mkd_fail(-1, "gemm: fused LayerNorm needs the producer's row statistics in 1..20 column slots");
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
+    if (a.gn_stat && (a.act == 2 || a.out_f32 || a.stat_out || a.gn_cg <= 0 || a.gn_hw <= 0 || a.gn_coff < 0 || (a.gn_coff + a.N + a.gn_cg - 1) / a.gn_cg > 32))
+        return mkd_fail(-1, "gemm: GroupNorm statistics need a plain bf16 output, rows per sample, channels per group, <= 32 groups");
     GemmPlan g;
     { const int rc = gemm_resolve_plan(a, &g); if (rc) return rc; }
     if (is_patch_cfg(g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
@@ -573,6 +673,12 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
 }
 
 int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream) {
+    if (a.gn_stat) {
+        dim3 rg((a.N / 4 + 63) / 64, (a.M + 15) / 16);
+        hipLaunchKernelGGL(splitk_epilogue_gn_kernel, rg, dim3(256), 0, stream, a);
+        MKD_LAUNCH_CHECK("splitk_epilogue_gn_kernel");
+        return 0;
+    }
     dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, a);
     MKD_LAUNCH_CHECK("splitk_epilogue_kernel");

@@ -8,8 +8,10 @@
 // (2) fold partials -> mean/rstd, apply gamma/beta (+SiLU), 16-B stores.
 // LayerNorm: one 64-lane wavefront per row, row kept in registers, wave-shuffle reductions.
 #include "mkd_common.h"
+#include "gemm_device.h"
 
 namespace {
+using mkdk::GN_FIX_SUM; using mkdk::GN_FIX_SQ; using mkdk::GN_GROUPS; using mkdk::gn_atomic_add;
 
 constexpr int GN_MAX_GROUPS = 32;
 
@@ -292,6 +294,128 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
     }
 }
 
+// GroupNorm APPLY with statistics that the producers of x already accumulated (gemm_device.h: gstat[sample][32][2], 64-bit
+// fixed point): no reduction, no dependency between workgroups - a plain element-wise kernel over (sample, row chunk) that
+// fills the chip.  threads = V * P, V = C / 8 vectors per pixel (a thread keeps its 8 channels: scale / shift in registers).
+__global__ __launch_bounds__(320) void gn_apply_stats_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y, int ld_out,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                             int silu, int hw, int C, int rows_per_block,
+                                                             const long long* __restrict__ gstat) {
+    __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+    const int V = C >> 3;
+    const int P = blockDim.x / V;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int cg = C / GN_GROUPS;
+    if (tid < GN_GROUPS) {
+        const long long a = gstat[((size_t)b * GN_GROUPS + tid) * 2], q = gstat[((size_t)b * GN_GROUPS + tid) * 2 + 1];
+        const double n = (double)hw * (double)cg;
+        const double mean = (double)a / ((double)GN_FIX_SUM * n);
+        double var = (double)q / ((double)GN_FIX_SQ * n) - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = rsqrtf((float)var + eps);
+    }
+    const int v = tid % V, pl = tid / V;
+    float pg[8], pb[8];
+    {
+        const f32x4 g0 = *(const f32x4*)(gamma + v * 8), g1 = *(const f32x4*)(gamma + v * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + v * 8), b1 = *(const f32x4*)(beta + v * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[j] = g0[j]; pg[4 + j] = g1[j]; pb[j] = b0[j]; pb[4 + j] = b1[j]; }
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(hw, r0 + rows_per_block);
+    const bf16_t* xin = x + (size_t)b * hw * ld_in + v * 8;
+    bf16_t* yout = y + (size_t)b * hw * ld_out + v * 8;
+    // the slab loads do not depend on the statistics: issue the first ones before the barrier
+    constexpr int U = 4;
+    U16x8 d[U];
+    int r = r0 + pl;
+    if (pl < P) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u * P < r1) d[u] = *(const U16x8*)(xin + (size_t)(r + u * P) * ld_in);
+    }
+    __syncthreads();
+    if (pl >= P) return;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (v * 8 + j) / cg;
+        const float a = pg[j] * s_rstd[g];
+        sa[j] = a;
+        sb[j] = pb[j] - s_mean[g] * a;
+    }
+    auto apply_store = [&](const U16x8& in, int row) {
+        U16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf16_to_f32(in.v[j]) * sa[j] + sb[j];
+            if (silu) f = silu_f(f);
+            o.v[j] = f32_to_bf16(f);
+        }
+        *(U16x8*)(yout + (size_t)row * ld_out) = o;
+    };
+    for (; r < r1; r += U * P) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u * P < r1) apply_store(d[u], r + u * P);
+        const int rn = r + U * P;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (rn + u * P < r1) d[u] = *(const U16x8*)(xin + (size_t)(rn + u * P) * ld_in);
+    }
+}
+
+// Fallback producer of the same statistics for tensors whose writer cannot emit them (the 4 -> C input convolution, plain
+// copies): columns [0, ncols) of x (a slice of a wider consumer tensor starting at consumer column coff).
+__global__ __launch_bounds__(320) void gn_colstats_kernel(const bf16_t* __restrict__ x, int ld, int hw, int ncols, int rows_per_block,
+                                                          int cg, int coff, long long* __restrict__ gstat) {
+    constexpr int CAP = 512;
+    __shared__ long long acc[CAP * 2];
+    const int V = ncols >> 3;                 // threads = V * P (launcher): thread -> (vector v, row lane pl)
+    const int P = blockDim.x / V;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int g_first = coff / cg;
+    const int ngl = (coff + ncols - 1) / cg - g_first + 1;
+    const bool use_lds = ngl <= CAP;
+    if (use_lds)
+        for (int i = tid; i < ngl * 2; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const int v = tid % V, pl = tid / V;
+    if (pl < P) {
+        const bf16_t* base = x + (size_t)b * hw * ld + v * 8;
+        float sm[8], sq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
+        for (int r = r0 + pl; r < r1; r += P) {          // all rows of a block belong to sample b
+            const U16x8 d = *(const U16x8*)(base + (size_t)r * ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(d.v[j]); sm[j] += f; sq[j] += f * f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gl = (coff + v * 8 + j) / cg - g_first;
+            const long long a = __float2ll_rn(sm[j] * GN_FIX_SUM), q = __float2ll_rn(sq[j] * GN_FIX_SQ);
+            long long* dst = use_lds ? acc + (size_t)gl * 2 : gstat + ((size_t)b * GN_GROUPS + g_first + gl) * 2;
+            if (a) gn_atomic_add(dst, a);
+            if (q) gn_atomic_add(dst + 1, q);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = tid; i < ngl; i += blockDim.x) {
+            const long long a = acc[i * 2], q = acc[i * 2 + 1];
+            long long* dst = gstat + ((size_t)b * GN_GROUPS + g_first + i) * 2;
+            if (a) gn_atomic_add(dst, a);
+            if (q) gn_atomic_add(dst + 1, q);
+        }
+    }
+}
+
 // one wave per row; NV = vectors of 8 per lane (d <= 64*8*NV)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
@@ -442,6 +566,44 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
                        hw, C, groups, rows_per_chunk, nchunks, partials);
     MKD_LAUNCH_CHECK("gn_apply_kernel");
+    return 0;
+}
+
+static int gn_thread_shape(int cols, int* threads) {
+    const int V = cols / 8;
+    if (cols % 8 || V < 1 || V > 320) return mkd_fail(-4, "groupnorm (fused statistics): channel count must be a multiple of 8 and <= 2560");
+    const int P = V >= 256 ? 1 : 256 / V;
+    *threads = V * P;
+    return 0;
+}
+
+int launch_gn_apply_stats(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
+                          int batch, int hw, int C, const long long* gstat, hipStream_t stream) {
+    if (C % 32 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C must be a multiple of 32 (and of 8), ld of 8");
+    if (!gstat) return mkd_fail(-1, "groupnorm: statistics missing");
+    int threads;
+    int rc = gn_thread_shape(C, &threads); if (rc) return rc;
+    const int P = threads / (C / 8);
+    int rpb = (int)(((long long)batch * hw + 511) / 512);           // ~512 blocks: two per CU
+    rpb = ((rpb + P - 1) / P) * P;
+    if (rpb < P) rpb = P;
+    dim3 grid((hw + rpb - 1) / rpb, batch);
+    hipLaunchKernelGGL(gn_apply_stats_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu, hw, C, rpb, gstat);
+    MKD_LAUNCH_CHECK("gn_apply_stats_kernel");
+    return 0;
+}
+
+int launch_gn_colstats(const bf16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, long long* gstat, hipStream_t stream) {
+    if (ld % 8 || cg <= 0 || coff < 0 || (coff + ncols + cg - 1) / cg > 32) return mkd_fail(-1, "gn_colstats: bad geometry");
+    int threads;
+    int rc = gn_thread_shape(ncols, &threads); if (rc) return rc;
+    const int P = threads / (ncols / 8);
+    int rpb = (int)(((long long)batch * hw + 255) / 256);
+    rpb = ((rpb + P - 1) / P) * P;
+    if (rpb < 4 * P) rpb = 4 * P;
+    dim3 grid((hw + rpb - 1) / rpb, batch);
+    hipLaunchKernelGGL(gn_colstats_kernel, grid, dim3(threads), 0, stream, x, ld, hw, ncols, rpb, cg, coff, gstat);
+    MKD_LAUNCH_CHECK("gn_colstats_kernel");
     return 0;
 }
 

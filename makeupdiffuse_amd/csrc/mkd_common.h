@@ -82,6 +82,9 @@ struct GemmArgs {
     const float* ln_s; float ln_eps;        // fused LayerNorm on the A rows: ln_s[n] = sum_k W'[n][k] (W' = W*gamma), else null
     const float* stat_in; int stat_in_slots; // ... whose row sums were emitted by the producer: [slots][M][2] (sum, sumsq)
     float* stat_out;                        // producer side: emit per-column-slot partial row sums of the (rounded) output
+    // GroupNorm statistics of the tensor this GEMM writes (part of): gn_stat[sample][32][2] int64 fixed point (gemm_device.h);
+    // gn_cg channels per group OF THE CONSUMER's tensor, gn_coff = column of this output inside it (concat halves), gn_hw rows per sample
+    long long* gn_stat; int gn_cg; int gn_coff; int gn_hw;
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
@@ -115,6 +118,11 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
                      hipStream_t stream);
 size_t groupnorm_partials_bytes(int batch, int hw, int groups);
+// GroupNorm with producer-emitted statistics (gstat[batch][32][2] int64 fixed point, see gemm_device.h): element-wise apply,
+// and the stand-alone producer of the same statistics for tensors whose writer cannot emit them
+int launch_gn_apply_stats(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
+                          int batch, int hw, int C, const long long* gstat, hipStream_t stream);
+int launch_gn_colstats(const bf16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, long long* gstat, hipStream_t stream);
 int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
                           bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream);
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,

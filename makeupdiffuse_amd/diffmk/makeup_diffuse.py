@@ -284,6 +284,7 @@ class BaseMakeUpDiffuse:
 class TestDiffuseModel(BaseMakeUpDiffuse):
     """Reference Test* harness classes (diffmk/diffusion_makeup.py:308-411, diffmk/makeup_diffuse.py:413-464):
     adds the sampling settings and ``log_results``' two DDIM passes."""
+    __test__ = False          # (pytest: a class named Test*, not a test case)
 
     def __init__(self, saved_dir: str = './results', model_name: str = 'makeupdiffuse', img_name_key: str = 'img_name',
                  unconditional_guidance_scale: float = 9, ddim_steps: int = 50, ddim_eta: float = 0.0, sample: bool = True,

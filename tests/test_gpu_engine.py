@@ -85,7 +85,8 @@ def test_small_sample_loop(small):
     sch = sampler.Schedule().make_ddim(5)
     eng.prepare(g['hint'], g['ctx'])
     out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
-    check_eps(out, g['x5'], rel=6e-2, cos=0.99, what='5-step latent')
+    r, c = check_eps(out, g['x5'], rel=1.5e-2, cos=0.9999, what='5-step latent')
+    print(f'[parity] 5-step latent: rel-L2 {r:.4e} cos {c:.6f}')
     # hipGraph replay of the same loop (one captured step, device-resident step counter) must not change the numbers
     outg = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                       use_graph=True)
@@ -97,7 +98,8 @@ def test_small_sample_loop(small):
     eng.prepare(torch.cat([g['hint'], g['hint']]), torch.cat([g['uctx'], g['ctx']]))
     out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                      cfg_scale=9.0)
-    check_eps(out, g['x5_cfg'], rel=0.15, cos=0.99, what='5-step CFG latent')
+    r, c = check_eps(out, g['x5_cfg'], rel=6e-2, cos=0.999, what='5-step CFG latent')      # measured ~2.4e-2 (4-step CFG 9, round 2)
+    print(f'[parity] 5-step CFG-9 latent: rel-L2 {r:.4e} cos {c:.6f}')
     outg = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                       cfg_scale=9.0, use_graph=True)
     assert torch.allclose(outg, out, rtol=1e-5, atol=1e-6), (outg - out).abs().max()

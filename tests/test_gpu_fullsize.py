@@ -91,7 +91,7 @@ def test_full_size_512_batch8_properties(full):
     eng.prepare(hint, ctx)
     a = eng.eps(x, t)
     assert torch.isfinite(a).all() and torch.equal(a, eng.eps(x, t))
-    sch = DDIMSchedule().make_ddim(3)
+    sch = DDIMSchedule().make_ddim(4)
     args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
     e = eng.sample(x, *args, use_graph=False)
     assert torch.isfinite(e).all() and torch.equal(e, eng.sample(x, *args, use_graph=True))
@@ -119,7 +119,7 @@ def test_full_size_interpolation_batch44_properties(full):
     eng.prepare(h1, ctx, hint2=h2, alpha=alpha)
     a = eng.eps(x, t)
     assert torch.isfinite(a).all() and torch.equal(a, eng.eps(x, t))
-    sch = DDIMSchedule().make_ddim(3)
+    sch = DDIMSchedule().make_ddim(4)
     args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
     e = eng.sample(x, *args, use_graph=False)
     assert torch.isfinite(e).all() and torch.equal(e, eng.sample(x, *args, use_graph=True))

@@ -2,8 +2,10 @@
 the live oracle: MKDDIMSampler.reconstruct / denoising_step (reference diffmk/cddim.py:9-100), apply_model(return_all=True)
 (makeup_diffuse.py:152-170), TestDiffuseModel.log_results' two passes (diffusion_makeup.py:391-410: plain 50 steps, then CFG 9
 with uc_cat = c_cat), generate_image / decode_latent_code (makeup_diffuse.py:172-177, makeups.py:119-127,260-262), and the
-50-step trajectories the harness really runs.  Tolerances: SURVEY.md §8c (bf16 compute vs fp32 oracle): one eps evaluation
-rel-L2 <= 2e-2 / cosine >= 0.9995; multi-step latents cosine >= 0.99.  The measured numbers are printed (-s shows them)."""
+50-step trajectories the harness really runs.  Tolerances: SURVEY.md §8c (bf16 compute vs fp32 oracle) asks for one eps
+evaluation rel-L2 <= 2e-2 / cosine >= 0.9995 and multi-step latents cosine >= 0.99; the multi-step limits below are TIGHTER,
+about 3x what was measured on MI355X in round 2 (50-step latent rel-L2 2.7e-3 / cos 0.999996, 50-step CFG-9 latent 1.5e-2 /
+0.99989, decoded image 8.7e-3, 4-step CFG-9 reconstruct 2.4e-2).  The measured numbers are printed (-s shows them)."""
 import os
 
 import numpy as np
@@ -100,14 +102,14 @@ def test_mkddim_sampler_on_device_vs_golden(model, G):
     uc = {'c_crossattn': [G['uctx'].cuda()], 'c_concat': c['c_concat']}
     x = G['x'].cuda()
     fast = s.reconstruct(x, c, t_start=4)
-    check(fast, G['rec4'], 6e-2, 0.99, 'reconstruct(t_start=4), mkd_sample path')
+    check(fast, G['rec4'], 1e-2, 0.9999, 'reconstruct(t_start=4), mkd_sample path')
     seen = []
     slow = s.reconstruct(x, c, t_start=4, callback=seen.append)
     assert seen == [0, 1, 2, 3]
-    check(slow, G['rec4'], 6e-2, 0.99, 'reconstruct(t_start=4), step-by-step path')
+    check(slow, G['rec4'], 1e-2, 0.9999, 'reconstruct(t_start=4), step-by-step path')
     check(slow, fast, 1e-5, 0.999999, 'step-by-step == in-library loop')
     fastc = s.reconstruct(x, c, t_start=4, unconditional_guidance_scale=9.0, unconditional_conditioning=uc)
-    check(fastc, G['rec4_cfg'], 6e-2, 0.99, 'reconstruct(t_start=4, CFG 9)')
+    check(fastc, G['rec4_cfg'], 6e-2, 0.999, 'reconstruct(t_start=4, CFG 9)')
     slowc = s.reconstruct(x, c, t_start=4, unconditional_guidance_scale=9.0, unconditional_conditioning=uc, callback=lambda i: None)
     check(slowc, fastc, 1e-5, 0.999999, 'CFG: step-by-step == in-library loop')
     ts = torch.full((x.shape[0],), int(s.ddim_timesteps[6]), device='cuda:0', dtype=torch.long)
@@ -126,9 +128,9 @@ def test_log_results_two_passes_vs_golden(model, G):
     unconditional branch; latents and decoded images against the oracle's sample() x 2 and decode_first_stage."""
     batch = {'src_img': G['hint'][:, :3], 'ref_img': G['hint'][:, 3:], 'txt_emb': G['ctx'], 'img_name': ['a&b', 'c&d']}
     log = model.log_results(batch, 0, x_T=G['x'].cuda())
-    check(log['samples_latent'], G['x50'], 6e-2, 0.99, '50-step latent (samples)')
-    check(log['samples_cfg_scale_9.00_latent'], G['x50_cfg'], 0.1, 0.99, '50-step CFG-9 latent (samples_cfg_scale_9.00)')
-    check(log['samples'], G['img50'], 8e-2, 0.99, '50-step decoded image')
+    check(log['samples_latent'], G['x50'], 1e-2, 0.9999, '50-step latent (samples)')
+    check(log['samples_cfg_scale_9.00_latent'], G['x50_cfg'], 5e-2, 0.999, '50-step CFG-9 latent (samples_cfg_scale_9.00)')
+    check(log['samples'], G['img50'], 3e-2, 0.999, '50-step decoded image')
     assert torch.equal(log['control_src'].cpu(), G['hint'][:, :3] * 2 - 1) and torch.equal(log['control_ref'].cpu(), G['hint'][:, 3:] * 2 - 1)
     assert model.test_pairs[-2:] == [['0000-1', 'non-makeup/a.png', 'makeup/b.png'], ['0000-2', 'non-makeup/c.png', 'makeup/d.png']]
 
@@ -220,7 +222,7 @@ def test_back_to_back_batches_do_not_reuse_conditioning(model, G, weights):
 def test_sample_rejects_a_latent_that_does_not_match_the_prepared_hint(model, G):
     eng = model.engine
     eng.prepare(G['hint'], G['ctx'])
-    sch = sampler.Schedule().make_ddim(3)
+    sch = sampler.Schedule().make_ddim(4)
     args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
     with pytest.raises(ValueError):
         eng.sample(torch.randn(2, 4, 4, 4), *args)             # smaller H, W than the hint implies
