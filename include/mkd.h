@@ -206,6 +206,22 @@ int mkd_gemm_cfg_supported(int cfg, int M, int N, int K, int conv3x3, int Hin, i
 /* GroupNorm(32 groups, fp32 statistics) [+SiLU] over NHWC bf16 (pixel stride ld_in). */
 int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps,
                   int silu, uint16_t* y, int ld_out, int batch, int hw, int C, int groups, void* stream);
+/* GroupNorm split in two so that the statistics pass disappears into the kernel that WRITES the tensor (UPSTREAM GroupNorm32 of
+ * ResBlock.in_layers/out_layers and SpatialTransformer.norm, reached from diffmk/makeup_diffuse.py:164-168):
+ *   gstat[batch][32][2] = (sum * 2^24, sum of squares * 2^18) as 64-bit integers, zeroed by the caller, accumulated with integer
+ *   atomics (order-independent, so results are bit-repeatable) by every producer of the tensor;
+ *   mkd_gemm_gnstat_bf16  = mkd_gemm_bf16 whose epilogue also adds the statistics of its bf16 output (columns gn_coff.. of a
+ *                           consumer tensor with gn_cg channels per group, gn_hw rows per sample);
+ *   mkd_gn_colstats       = stand-alone producer of the same statistics for columns [0, ncols) of x;
+ *   mkd_gn_apply_stats    = y = (x - mean) * rstd * gamma + beta [-> SiLU], element-wise, statistics read from gstat. */
+int mkd_gemm_gnstat_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                         const float* rowbias, int ldrb, int rows_per_batch,
+                         const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M, int N, int K,
+                         int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
+                         int stride, int upsample, int splitk, int64_t* gn_stat, int gn_cg, int gn_coff, int gn_hw, void* stream);
+int mkd_gn_colstats(const uint16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, int64_t* gstat, void* stream);
+int mkd_gn_apply_stats(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,
+                       int ld_out, int batch, int hw, int C, const int64_t* gstat, void* stream);
 /* LayerNorm over the last dim of [rows, d] bf16. */
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
                   uint16_t* y, int rows, int d, void* stream);

@@ -27,8 +27,22 @@ namespace {
 struct Tensor {
     bf16_t* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0, ld = 0;
+    // GroupNorm statistics of this tensor, accumulated by the kernels that WRITE it (gemm_device.h): [B][32][2] int64, or null
+    // when the GroupNorm that reads it computes them itself
+    long long* gst = nullptr;
     int rows() const { return B * H * W; }
 };
+
+// where a producer adds the GroupNorm statistics of what it writes: buffer of the consumer tensor, its channels per group, the
+// column this output starts at inside it (concat halves), rows per sample
+struct GnOut {
+    long long* gst = nullptr; int cg = 0, coff = 0, hw = 0;
+};
+static GnOut gn_of(const Tensor& t, int coff = 0) {
+    GnOut g;
+    if (t.gst) { g.gst = t.gst; g.cg = t.C / 32; g.coff = coff; g.hw = t.H * t.W; }
+    return g;
+}
 
 struct BlockSpec {
     int kind;  // 0 conv_in, 1 res, 2 down
@@ -68,6 +82,7 @@ struct Epi {
     const float* ln_s = nullptr;          // fused LayerNorm of the A rows (weights pre-folded with gamma/beta)
     const float* stat_in = nullptr; int stat_slots = 0;   // ... with the row sums the producer GEMM emitted
     float* stat_out = nullptr;            // emit row sums of this GEMM's output for a downstream fused LayerNorm
+    GnOut gn;                             // emit GroupNorm statistics of this GEMM's output
 };
 
 typedef std::function<int(hipStream_t)> OpFn;
@@ -104,6 +119,10 @@ struct mkd_ctx {
     // but measured neutral-to-slower in the pipeline (the consumer inherits the producer's write-back wait that the
     // LayerNorm kernel used to absorb), so it is opt-in: MKD_FUSE_LN=1.
     bool fuse_ln = false;
+    // GroupNorm statistics emitted by the producing kernel's epilogue (deterministic fixed-point atomics) + an element-wise apply
+    // kernel, instead of the two-phase GroupNorm kernel (MKD_GN_FUSED=0: the stand-alone kernel everywhere)
+    bool gn_fused = getenv("MKD_GN_FUSED") ? atoi(getenv("MKD_GN_FUSED")) != 0 : true;
+    Arena gstat; char* gstat_base = nullptr; size_t gstat_cap = 0;
 
     // fused weights (built in finalize)
     std::map<std::string, bf16_t*> qkv_w, kv_w;   // by transformer prefix
@@ -569,7 +588,8 @@ struct mkd_ctx {
              "M=" + std::to_string(a.M) + " N=" + std::to_string(a.N) + " K=" + std::to_string(a.K) + " conv=" + std::to_string(a.conv) +
              " stride=" + std::to_string(a.stride) + " up=" + std::to_string(a.up) + " splitk=" + std::to_string(s) +
              " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32) + " Hin=" + std::to_string(a.Hin) +
-             " Win=" + std::to_string(a.Win) + " Cin=" + std::to_string(a.Cin) + " Hout=" + std::to_string(a.Hout) + " Wout=" + std::to_string(a.Wout));
+             " Win=" + std::to_string(a.Win) + " Cin=" + std::to_string(a.Cin) + " Hout=" + std::to_string(a.Hout) + " Wout=" + std::to_string(a.Wout) +
+             " gn=" + std::to_string(a.gn_stat != nullptr));
     }
     void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
         GemmArgs a; memset(&a, 0, sizeof(a));
@@ -577,6 +597,7 @@ struct mkd_ctx {
         a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
         a.C = C; a.ldc = ldc; a.out_f32 = f32out ? 1 : 0; a.M = M; a.N = N; a.K = K; a.conv = 0;
         a.ln_s = e.ln_s; a.ln_eps = 1e-5f; a.stat_in = e.stat_in; a.stat_in_slots = e.stat_slots; a.stat_out = e.stat_out;
+        a.gn_stat = e.gn.gst; a.gn_cg = e.gn.cg; a.gn_coff = e.gn.coff; a.gn_hw = e.gn.hw;
         op_gemm(a);
     }
     // 3x3 conv, pad 1; returns output spatial dims through Hout/Wout
@@ -588,9 +609,17 @@ struct mkd_ctx {
         a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
         a.C = C; a.ldc = ldc; a.out_f32 = 0; a.M = in.B * Ho * Wo; a.N = N; a.K = 9 * in.C; a.conv = 1;
         a.Hin = in.H; a.Win = in.W; a.Cin = in.C; a.Hout = Ho; a.Wout = Wo; a.stride = stride; a.up = up;
+        a.gn_stat = e.gn.gst; a.gn_cg = e.gn.cg; a.gn_coff = e.gn.coff; a.gn_hw = e.gn.hw;
         op_gemm(a);
     }
     void op_gn(const Tensor& in, const float* gamma, const float* beta, float eps, int silu, bf16_t* out, int ld_out) {
+        if (in.gst) {          // statistics were accumulated by the producers of `in`: element-wise apply
+            Tensor t = in;
+            push(*cur_plan, [t, gamma, beta, eps, silu, out, ld_out](hipStream_t st) {
+                return launch_gn_apply_stats(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, t.gst, st);
+            }, 1, 0.0, K_GROUPNORM, "apply B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
+            return;
+        }
         const size_t need = groupnorm_partials_bytes(in.B, in.H * in.W, 32);
         if (need > gn_need) gn_need = need;
         mkd_ctx* self = this;
@@ -622,7 +651,7 @@ struct mkd_ctx {
     // side_skip: run the 1x1 skip_connection GEMM on the side stream, concurrently with GN -> conv -> GN (decoder only:
     // the side stream is idle there).
     void resblock(const std::string& p, const Tensor& x, int cout, const float* embproj, int ld_emb, bf16_t* out, int ldo,
-                  bool side_skip = false) {
+                  bool side_skip = false, const GnOut& go = GnOut()) {
         const size_t mk = TA().mark();
         const int rows = x.rows(), hw = x.H * x.W;
         Tensor t4;
@@ -637,11 +666,12 @@ struct mkd_ctx {
         Tensor t1 = talloc(TA(), x.B, x.H, x.W, x.C);
         op_gn(x, wf(p + ".in_layers.0.weight"), wf(p + ".in_layers.0.bias"), 1e-5f, 1, t1.p, t1.ld);
         Tensor t2 = talloc(TA(), x.B, x.H, x.W, cout);
-        Epi e1; e1.bias = wf(p + ".in_layers.2.bias"); e1.rowbias = embproj + emb_off.at(p); e1.ldrb = ld_emb; e1.rpb = hw;
+        want_stats(t2);
+        Epi e1; e1.bias = wf(p + ".in_layers.2.bias"); e1.rowbias = embproj + emb_off.at(p); e1.ldrb = ld_emb; e1.rpb = hw; e1.gn = gn_of(t2);
         op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
         Tensor t3 = talloc(TA(), x.B, x.H, x.W, cout);
         op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
-        Epi e2; e2.bias = wf(p + ".out_layers.3.bias");
+        Epi e2; e2.bias = wf(p + ".out_layers.3.bias"); e2.gn = go;
         if (x.C != cout && side_skip) {
             op_edge(helper_stream, lane_main);           // the lane waits for the skip GEMM
             e2.R = t4.p; e2.ldr = t4.ld;
@@ -660,7 +690,7 @@ struct mkd_ctx {
     // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
     // b0: first sample of x inside the prepared batch (decoder lanes run on a batch slice; the cross-attention K/V cache is
     // indexed by absolute sample)
-    void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo, int b0 = 0) {
+    void spatial_transformer(const std::string& p, const Tensor& x, bf16_t* out, int ldo, int b0 = 0, const GnOut& go = GnOut()) {
         const size_t mk = TA().mark();
         const int d = x.C, M = x.rows(), T = x.H * x.W, heads = cfg.num_heads, dh = d / heads;
         const std::string t = p + ".transformer_blocks.0";
@@ -715,13 +745,13 @@ struct mkd_ctx {
           else e.bias = ffp_b.at(p);
           op_linear(a_in, d, M, d, fl ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, ldg); }
         if (mf) {
-            Epi e; e.bias = ffm_b.at(p); e.R = x.p; e.ldr = x.ld;
+            Epi e; e.bias = ffm_b.at(p); e.R = x.p; e.ldr = x.ld; e.gn = go;
             op_linear(cat5, 5 * d, M, 5 * d, ffm_w.at(p), d, e, out, ldo);
         } else {
             bf16_t* h3 = buf(d);
             { Epi e; e.bias = wf(t + ".ff.net.2.bias"); e.R = h2; e.ldr = d;
               op_linear(gg, 4 * d, M, 4 * d, wb(t + ".ff.net.2.weight"), d, e, h3, d); }
-            { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld;
+            { Epi e; e.bias = wf(p + ".proj_out.bias"); e.R = x.p; e.ldr = x.ld; e.gn = go;
               op_linear(h3, d, M, d, wb(p + ".proj_out.weight"), d, e, out, ldo); }
         }
         TA().release(mk);
@@ -745,7 +775,24 @@ struct mkd_ctx {
         return proj;
     }
 
-    static Tensor slice(Tensor t, int b0, int nb) { t.p += (size_t)b0 * t.H * t.W * t.ld; t.B = nb; return t; }
+    static Tensor slice(Tensor t, int b0, int nb) {
+        t.p += (size_t)b0 * t.H * t.W * t.ld;
+        if (t.gst) t.gst += (size_t)b0 * 64;
+        t.B = nb;
+        return t;
+    }
+    // this tensor will be read by a GroupNorm: give it a statistics buffer that its producers fill
+    void want_stats(Tensor& t) {
+        t.gst = nullptr;
+        if (!gn_fused || t.C % 32 || t.C % 8 || t.C / 8 > 320) return;
+        t.gst = (long long*)gstat.alloc((size_t)t.B * 64 * sizeof(long long));
+    }
+    // producers that cannot emit statistics themselves (direct convolution, copies): a stand-alone pass over what they wrote
+    void op_colstats(const bf16_t* x, int ld, int nb, int hw, int ncols, const GnOut& g) {
+        if (!g.gst) return;
+        push(*cur_plan, [=](hipStream_t st) { return launch_gn_colstats(x, ld, nb, hw, ncols, g.cg, g.coff, g.gst, st); }, 1, 0.0, K_GROUPNORM,
+             "colstats B=" + std::to_string(nb) + " HW=" + std::to_string(hw) + " C=" + std::to_string(ncols));
+    }
 
     // whole-batch outputs of one net's encoder: feats[i] = output of input_blocks[i]; mid = middle block output
     void alloc_encoder(std::vector<Tensor>& feats, Tensor& mid) {
@@ -754,6 +801,8 @@ struct mkd_ctx {
         for (size_t i = 0; i < enc.size(); ++i) {
             if (enc[i].kind == 2) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
             feats.push_back(talloc(persist, B, H, W, enc[i].cout));
+            // read by a GroupNorm when the next block is a ResBlock (the last one feeds middle_block.0); a Downsample conv reads it raw
+            if (i + 1 == enc.size() || enc[i + 1].kind == 1) want_stats(feats.back());
         }
         mid = talloc(persist, B, H, W, enc.back().cout);
     }
@@ -778,18 +827,20 @@ struct mkd_ctx {
                 push(*cur_plan, [self, wgt, bias, o, add, nb, hh, ww, cin, cout, xoff](hipStream_t st) {
                     return launch_conv3x3_direct(self->io_x + xoff, 1, wgt, bias, o.p, 0, 0, add, nb, hh, ww, cin, cout, 1, st);
                 }, 1, 2.0 * nb * h * w * b.cout * 9 * b.cin, K_CONV_DIRECT);
+                op_colstats(o.p, o.ld, o.B, o.H * o.W, o.C, gn_of(o));
             } else if (b.kind == 1) {
                 if (b.attn) {
                     const size_t mk = TA().mark();
                     Tensor r = talloc(TA(), hcur.B, hcur.H, hcur.W, b.cout);
-                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, r.p, r.ld);
-                    spatial_transformer(p + ".1", r, o.p, o.ld, b0);
+                    want_stats(r);
+                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, r.p, r.ld, false, gn_of(r));
+                    spatial_transformer(p + ".1", r, o.p, o.ld, b0, gn_of(o));
                     TA().release(mk);
                 } else {
-                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, o.p, o.ld);
+                    resblock(p + ".0", hcur, b.cout, embproj, ld_emb, o.p, o.ld, false, gn_of(o));
                 }
             } else {
-                Epi e; e.bias = wf(p + ".0.op.bias");
+                Epi e; e.bias = wf(p + ".0.op.bias"); e.gn = gn_of(o);
                 op_conv(hcur, wb(p + ".0.op.weight"), b.cout, 2, 0, e, o.p, o.ld);
             }
             hcur = o;
@@ -797,9 +848,11 @@ struct mkd_ctx {
         const int ch = hcur.C;
         const size_t mk = TA().mark();
         Tensor m1 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
-        resblock(P + "middle_block.0", hcur, ch, embproj, ld_emb, m1.p, m1.ld);
+        want_stats(m1);
+        resblock(P + "middle_block.0", hcur, ch, embproj, ld_emb, m1.p, m1.ld, false, gn_of(m1));
         Tensor m2 = talloc(TA(), hcur.B, hcur.H, hcur.W, ch);
-        spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld, b0);
+        want_stats(m2);
+        spatial_transformer(P + "middle_block.1", m1, m2.p, m2.ld, b0, gn_of(m2));
         const Tensor m3 = slice(mid, b0, nb);
         resblock(P + "middle_block.2", m2, ch, embproj, ld_emb, m3.p, m3.ld);
         TA().release(mk);
@@ -884,6 +937,12 @@ struct mkd_ctx {
         const int EL = (enc_lanes && B >= 2) ? 2 : 1;
         float* ep0 = nullptr; float* ep1 = nullptr;
         cur_plan = &plan_eps;
+        cur_sid = 0;
+        if (gn_fused)           // the GroupNorm statistics of this evaluation start from zero (one memset node for all of them)
+            push(*cur_plan, [self](hipStream_t st) {
+                if (self->gstat.high) MKD_HIP_CHECK(hipMemsetAsync(self->gstat_base, 0, self->gstat.high, st));
+                return 0;
+            }, 1, 0.0, K_MISC, "gn_stat_zero");
         if (has_control) op_edge(0, 1, true, true);      // side stream starts after everything already enqueued by the caller
         cur_sid = 0; ep0 = time_embedding(0);
         if (has_control) { cur_sid = 1; ep1 = time_embedding(1); }
@@ -919,9 +978,11 @@ struct mkd_ctx {
             int Hc = hs[n_skip - 1].H, Wc = hs[n_skip - 1].W;
             for (size_t i = 0; i < dec.size(); ++i) {
                 cats[i] = talloc(persist, B, Hc, Wc, dec[i].cin);
+                want_stats(cats[i]);
                 if (dec[i].up) { Hc *= 2; Wc *= 2; }
             }
             final_t = talloc(persist, B, Hc, Wc, dec.back().cout);
+            want_stats(final_t);
         }
         // One decoder pass over samples [b0, b0 + nb).  helpers_on_side: the zero-conv "combine" GEMMs (skip + scale *
         // zero_conv(cn_feat), written straight into the concat buffer's skip half) and the ResBlocks' 1x1 skip GEMMs only depend
@@ -942,17 +1003,21 @@ struct mkd_ctx {
                     if (has_control) {
                         const Tensor cm = slice(cn_mid, b0, nb);
                         Epi e; e.bias = wf(PC + "middle_block_out.0.bias"); e.scale = scales[n_ctrl() - 1]; e.R = um.p; e.ldr = um.ld;
+                        e.gn = gn_of(cat, 0);
                         op_linear(cm.p, cm.ld, cm.rows(), cm.C, wb(PC + "middle_block_out.0.weight"), cm.C, e, cat.p, cat.ld);
                     } else {
                         op_copy(um.p, um.ld, cat.p, cat.ld, um.rows(), um.C);
+                        op_colstats(cat.p, cat.ld, cat.B, cat.H * cat.W, um.C, gn_of(cat, 0));
                     }
                 }
                 if (has_control && !only_mid) {
                     const Tensor cf = slice(cn_feats[si], b0, nb);
                     Epi e; e.bias = wf(PC + "zero_convs." + std::to_string(si) + ".0.bias"); e.scale = scales[si]; e.R = skip.p; e.ldr = skip.ld;
+                    e.gn = gn_of(cat, ch_h);
                     op_linear(cf.p, cf.ld, cf.rows(), cf.C, wb(PC + "zero_convs." + std::to_string(si) + ".0.weight"), cf.C, e, cat.p + ch_h, cat.ld);
                 } else {
                     op_copy(skip.p, skip.ld, cat.p + ch_h, cat.ld, skip.rows(), skip.C);
+                    op_colstats(cat.p + ch_h, cat.ld, cat.B, cat.H * cat.W, skip.C, gn_of(cat, ch_h));
                 }
             };
             if (helpers_on_side) op_edge(main_sid, helper_stream);     // helper: both encoders are complete (joined on the lane's stream)
@@ -971,25 +1036,31 @@ struct mkd_ctx {
                 const int stages = 1 + (bs.attn ? 1 : 0) + (bs.up ? 1 : 0);
                 Tensor cur_in = cat;
                 int stage = 0;
+                const GnOut go_dst = gn_of(nxt, 0);          // the block's last kernel also accumulates the next GroupNorm's statistics
                 {   // ResBlock
                     ++stage;
-                    bf16_t* op_; int ol;
-                    if (stage == stages) { op_ = dst; ol = dst_ld; }
-                    else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout); op_ = o.p; ol = o.ld; }
-                    resblock(p + ".0", cur_in, bs.cout, ep0 + (size_t)b0 * emb_total[0], emb_total[0], op_, ol, /*side_skip=*/helpers_on_side);
-                    cur_in.p = op_; cur_in.C = bs.cout; cur_in.ld = ol;
+                    Tensor o;
+                    GnOut go;
+                    if (stage == stages) { o = nxt; o.C = bs.cout; o.gst = nullptr; go = go_dst; }
+                    else {
+                        o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout);
+                        if (bs.attn) { want_stats(o); go = gn_of(o); }      // read by the transformer's GroupNorm (an Upsample conv reads it raw)
+                    }
+                    resblock(p + ".0", cur_in, bs.cout, ep0 + (size_t)b0 * emb_total[0], emb_total[0], o.p, o.ld, /*side_skip=*/helpers_on_side, go);
+                    cur_in = o;
                 }
                 if (bs.attn) {
                     ++stage;
-                    bf16_t* op_; int ol;
-                    if (stage == stages) { op_ = dst; ol = dst_ld; }
-                    else { Tensor o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout); op_ = o.p; ol = o.ld; }
-                    spatial_transformer(p + ".1", cur_in, op_, ol, b0);
-                    cur_in.p = op_; cur_in.ld = ol;
+                    Tensor o;
+                    GnOut go;
+                    if (stage == stages) { o = nxt; o.C = bs.cout; o.gst = nullptr; go = go_dst; }
+                    else o = talloc(TA(), cat.B, cat.H, cat.W, bs.cout);
+                    spatial_transformer(p + ".1", cur_in, o.p, o.ld, b0, go);
+                    cur_in = o;
                 }
                 if (bs.up) {
                     const int k = bs.attn ? 2 : 1;
-                    Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias");
+                    Epi e; e.bias = wf(p + "." + std::to_string(k) + ".conv.bias"); e.gn = go_dst;
                     op_conv(cur_in, wb(p + "." + std::to_string(k) + ".conv.weight"), bs.cout, 1, 1, e, dst, dst_ld);
                 }
                 TA().release(mk);
@@ -1074,12 +1145,14 @@ struct mkd_ctx {
             // pass 1: dry run to size the arenas (pointers are offsets from null and never dereferenced)
             dry = true;
             persist.base = nullptr; persist.reset();
+            gstat.base = nullptr; gstat.reset();
             for (int i = 0; i < NS; ++i) { temp_arena[i].base = nullptr; temp_arena[i].reset(); }
             splitk_need = 0; gn_need = 0;
             plan_prepare.clear(); plan_eps.clear();
             cur_sid = 0;
             build_prepare_plan(); build_eps_plan();
             int rc = ensure((void**)&persist_base, &persist_cap, persist.high + 256); if (rc) return rc;
+            rc = ensure((void**)&gstat_base, &gstat_cap, gstat.high + 256); if (rc) return rc;
             for (int i = 0; i < NS; ++i) {
                 rc = ensure((void**)&temp_base[i], &temp_cap[i], temp_arena[i].high + 256); if (rc) return rc;
                 rc = ensure((void**)&splitk_ws[i], &splitk_ws_bytes[i], splitk_need); if (rc) return rc;
@@ -1090,6 +1163,7 @@ struct mkd_ctx {
             // pass 2: real plan
             dry = false;
             persist.base = persist_base; persist.reset();
+            gstat.base = gstat_base; gstat.reset();
             for (int i = 0; i < NS; ++i) { temp_arena[i].base = temp_base[i]; temp_arena[i].reset(); }
             cur_sid = 0; aux_used = 0;
             build_prepare_plan();
@@ -1633,6 +1707,7 @@ struct mkd_ctx {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_debug_poison before mkd_prepare");
         MKD_HIP_CHECK(hipDeviceSynchronize());
         if (persist_cap > persist_eps_begin) MKD_HIP_CHECK(hipMemset(persist_base + persist_eps_begin, 0xFF, persist_cap - persist_eps_begin));
+        if (gstat_base) MKD_HIP_CHECK(hipMemset(gstat_base, 0xFF, gstat_cap));
         for (int i = 0; i < NS; ++i) {
             if (temp_base[i]) MKD_HIP_CHECK(hipMemset(temp_base[i], 0xFF, temp_cap[i]));
             if (splitk_ws[i]) MKD_HIP_CHECK(hipMemset(splitk_ws[i], 0xFF, splitk_ws_bytes[i]));
@@ -1643,11 +1718,12 @@ struct mkd_ctx {
     }
 
     int64_t device_bytes() const {
-        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + [&] { int64_t t = 0; for (int i = 0; i < NA; ++i) t += (int64_t)(temp_cap[i] + splitk_ws_bytes[i] + gn_ws_bytes[i]); return t; }();
+        return weight_bytes + (int64_t)varena_cap + (int64_t)carena_cap + (int64_t)persist_cap + (int64_t)gstat_cap + [&] { int64_t t = 0; for (int i = 0; i < NA; ++i) t += (int64_t)(temp_cap[i] + splitk_ws_bytes[i] + gn_ws_bytes[i]); return t; }();
     }
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
+        if (gstat_base) hipFree(gstat_base);
         if (varena_base) hipFree(varena_base);
         if (carena_base) hipFree(carena_base);
         for (auto& kv : f32_keep) hipFree(kv.second);
@@ -1821,10 +1897,10 @@ static int scratch(float** p, size_t* have, size_t need) {
     return 0;
 }
 
-int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
-                  int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,
-                  int N, int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up,
-                  int splitk, void* stream) {
+static int gemm_entry(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
+                      int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,
+                      int N, int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up,
+                      int splitk, long long* gn_stat, int gn_cg, int gn_coff, int gn_hw, void* stream) {
     if (!A || !W || !C) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_bf16: null pointer");
     if (!g_zero) {
         MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
@@ -1836,6 +1912,7 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
     a.R = R; a.ldr = ldr; a.scale = scale; a.act = act; a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.M = M; a.N = N; a.K = K;
     a.conv = conv3x3 ? 1 : 0; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
     a.zero = g_zero;
+    a.gn_stat = gn_stat; a.gn_cg = gn_cg; a.gn_coff = gn_coff; a.gn_hw = gn_hw;
     a.splitk = splitk > 0 ? splitk : 0;
     int cfg_i = 0, s = 1;
     int rc = gemm_resolve(a, &cfg_i, &s);          // the decision launch_gemm will take, fallbacks included
@@ -1844,6 +1921,30 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
     if (rc) return rc;
     a.ws = g_ws; a.ws_bytes = g_ws_bytes;
     return launch_gemm(a, (hipStream_t)stream);
+}
+int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
+                  int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,
+                  int N, int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up,
+                  int splitk, void* stream) {
+    return gemm_entry(A, lda, W, ldw, bias, rowbias, ldrb, rows_per_batch, R, ldr, scale, act, C, ldc, out_f32, M, N, K, conv3x3, batch,
+                      Hin, Win, Cin, Hout, Wout, stride, up, splitk, nullptr, 0, 0, 0, stream);
+}
+int mkd_gemm_gnstat_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
+                         int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,
+                         int N, int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up,
+                         int splitk, int64_t* gn_stat, int gn_cg, int gn_coff, int gn_hw, void* stream) {
+    if (!gn_stat) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_gnstat_bf16: null statistics buffer");
+    return gemm_entry(A, lda, W, ldw, bias, rowbias, ldrb, rows_per_batch, R, ldr, scale, act, C, ldc, out_f32, M, N, K, conv3x3, batch,
+                      Hin, Win, Cin, Hout, Wout, stride, up, splitk, (long long*)gn_stat, gn_cg, gn_coff, gn_hw, stream);
+}
+int mkd_gn_colstats(const uint16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, int64_t* gstat, void* stream) {
+    if (!x || !gstat) return mkd_fail(MKD_ERR_ARG, "mkd_gn_colstats: null pointer");
+    return launch_gn_colstats(x, ld, batch, hw, ncols, cg, coff, (long long*)gstat, (hipStream_t)stream);
+}
+int mkd_gn_apply_stats(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,
+                       int ld_out, int batch, int hw, int C, const int64_t* gstat, void* stream) {
+    if (!x || !y || !gamma || !beta || !gstat) return mkd_fail(MKD_ERR_ARG, "mkd_gn_apply_stats: null pointer");
+    return launch_gn_apply_stats(x, ld_in, gamma, beta, eps, silu, y, ld_out, batch, hw, C, (const long long*)gstat, (hipStream_t)stream);
 }
 int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K, uint16_t* w_out,
                        int dst_row0, int dst_row_mul, float* s_out, float* b_out, void* stream) {

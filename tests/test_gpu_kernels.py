@@ -393,3 +393,131 @@ def test_patch_entry_on_a_geometry_it_does_not_fit_falls_back_with_a_big_enough_
     finally:
         lib.mkd_gemm_set_override(0, 0, 0, 0, 0, 0, 0, 0)
     assert_close_bf16(out.float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what='patch override on an unsupported geometry')
+
+
+# ---- GroupNorm with producer-emitted statistics ---------------------------------------------------------------------------
+def _ref_gstat(out_bhwc, cg, coff):
+    """float64 (sum, sumsq) per (sample, consumer group) of a [B, hw, N] tensor sitting at consumer column coff."""
+    B, hw, N = out_bhwc.shape
+    o = out_bhwc.double()
+    S = torch.zeros(B, 32, 2, dtype=torch.float64)
+    for c in range(N):
+        gidx = (coff + c) // cg
+        S[:, gidx, 0] += o[:, :, c].sum(1).cpu()
+        S[:, gidx, 1] += (o[:, :, c] ** 2).sum(1).cpu()
+    return S
+
+
+def _check_gstat(gst, out_bhwc, cg, coff, what):
+    ref = _ref_gstat(out_bhwc, cg, coff)
+    got = torch.stack([gst[..., 0].double().cpu() / 2 ** 24, gst[..., 1].double().cpu() / 2 ** 18], -1)
+    n = out_bhwc.shape[1] * cg
+    # fp32 partial sums of <= 128 values + fixed-point rounding: absolute error per element far below the GroupNorm eps
+    err_s = ((got[..., 0] - ref[..., 0]).abs() / n).max().item()
+    err_q = ((got[..., 1] - ref[..., 1]).abs() / n).max().item()
+    scale = max(1.0, (ref[..., 1] / n).max().item())
+    assert err_s <= 2e-6 * scale ** 0.5 and err_q <= 2e-6 * scale, f'{what}: mean error {err_s:.2e}, mean-square error {err_q:.2e} (scale {scale:.1f})'
+
+
+@pytest.mark.parametrize('B,hw,C,silu,eps,pad', [(2, 64, 320, 1, 1e-5, 0), (3, 256, 640, 0, 1e-6, 0), (2, 16, 2560, 1, 1e-5, 0),
+                                                (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0),
+                                                (1, 4096, 960, 1, 1e-5, 0), (1, 64, 1920, 1, 1e-5, 0), (5, 12, 128, 1, 1e-5, 0), (8, 16, 1280, 0, 1e-6, 0)])
+def test_groupnorm_split_stats_then_apply(B, hw, C, silu, eps, pad):
+    """mkd_gn_colstats (stand-alone statistics) + mkd_gn_apply_stats == torch group_norm; statistics vs float64 sums; two
+    column slices (a concat of two producers) accumulate into the same buffer; bit-repeatable."""
+    lib = L()
+    g = torch.Generator().manual_seed(C + hw)
+    x = bf(torch.randn(B, hw, C + pad, generator=g) * 2 + 0.5)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV); beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    cg = C // 32
+    split = (C // 3) // 8 * 8 or 8                       # first "producer" writes columns [0, split), the second the rest
+    runs = []
+    for _ in range(2):
+        gst = torch.zeros(B, 32, 2, device=DEV, dtype=torch.int64)
+        assert lib.mkd_gn_colstats(P(x), C + pad, B, hw, split, cg, 0, P(gst), None) == 0, lib.mkd_last_error()
+        assert lib.mkd_gn_colstats(P(x[:, :, split:]), C + pad, B, hw, C - split, cg, split, P(gst), None) == 0, lib.mkd_last_error()
+        sync()
+        runs.append(gst)
+    assert torch.equal(runs[0], runs[1])
+    _check_gstat(runs[0], x[..., :C], cg, 0, 'colstats')
+    y = torch.zeros(B, hw, C, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_gn_apply_stats(P(x), C + pad, P(gamma), P(beta), eps, silu, P(y), C, B, hw, C, P(runs[0]), None) == 0, lib.mkd_last_error()
+    sync()
+    ref = F.group_norm(x[..., :C].float().permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert_close_bf16(y.float().permute(0, 2, 1), ref, what='groupnorm (split statistics)')
+
+
+def _gemm_gn(A, W, bias, M, N, K, cv, splitk, gst, cg, coff, hw, R=None, ldc=None, lda=None):
+    lib = L()
+    ldc_ = N if ldc is None else ldc
+    out = torch.zeros((M, ldc_), device=DEV, dtype=torch.bfloat16)
+    rc = lib.mkd_gemm_gnstat_bf16(P(A), A.stride(0) if lda is None else lda, P(W), K, P(bias), None, 0, 1, P(R), 0 if R is None else R.stride(0),
+                                  1.0, 0, P(out), ldc_, 0, M, N, K, *cv, splitk, P(gst), cg, coff, hw, None)
+    return rc, out
+
+
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize('B,hw,N,K,cg,coff,splitk', [(3, 64, 320, 320, 10, 0, 1), (2, 256, 640, 192, 30, 320, 1), (5, 16, 1280, 256, 80, 1280, 1),
+                                                     (7, 12, 64, 64, 6, 128, 1), (2, 64, 320, 1280, 10, 0, 4)])
+def test_gemm_epilogue_emits_groupnorm_statistics(cfg, B, hw, N, K, cg, coff, splitk):
+    """Every gather-GEMM tile configuration (and the split-K reduce kernel): the statistics a GEMM adds for its output equal the
+    float64 sums of the bf16 tensor it stored - tiles spanning several samples (hw 12 / 16), several tiles per sample, groups
+    that straddle column tiles (cg 10 / 30 / 6), an output that is the second half of a concat (coff > 0) - and are bit-repeatable."""
+    lib = L()
+    M = B * hw
+    g = torch.Generator().manual_seed(cfg * 13 + M + N)
+    A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g).to(DEV); R = bf(torch.randn(M, N, generator=g))
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        res = []
+        for _ in range(2):
+            gst = torch.zeros(B, 32, 2, device=DEV, dtype=torch.int64)
+            rc, out = _gemm_gn(A, W, bias, M, N, K, (0, 0, 0, 0, 0, 0, 0, 1, 0), splitk, gst, cg, coff, hw, R=R)
+            assert rc == 0, lib.mkd_last_error()
+            sync()
+            res.append((gst, out))
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert_close_bf16(res[0][1], A.float() @ W.float().t() + bias + R.float(), what=f'gemm+gn cfg {cfg}')
+    _check_gstat(res[0][0], res[0][1].view(B, hw, N), cg, coff, f'gemm statistics cfg {cfg}')
+    used = torch.zeros(32, dtype=torch.bool); used[coff // cg:(coff + N - 1) // cg + 1] = True
+    assert (res[0][0].cpu()[:, ~used] == 0).all()
+
+
+@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 3, 5])
+@pytest.mark.parametrize('B,H,W_,Cin,Cout,cg,coff,splitk', [(2, 32, 32, 64, 320, 10, 0, 1), (8, 4, 4, 128, 1280, 40, 0, 2), (3, 8, 8, 320, 640, 30, 320, 1),
+                                                           (5, 4, 4, 128, 192, 6, 0, 1), (2, 16, 16, 128, 64, 2, 0, 2)])
+def test_conv_epilogue_emits_groupnorm_statistics(cfg, B, H, W_, Cin, Cout, cg, coff, splitk):
+    """The LDS-staged 3x3 tiles (spatial tiles: one segment per image of the block, ragged image groups) and the gather conv, with
+    and without split-K over channel chunks."""
+    lib = L()
+    M = B * H * W_
+    g = torch.Generator().manual_seed(cfg * 17 + M + Cout)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    xn = xb.permute(0, 2, 3, 1).contiguous()
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(wbf.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    ref = F.conv2d(xb.float(), wbf.float(), bias, padding=1)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        res = []
+        for _ in range(2):
+            gst = torch.zeros(B, 32, 2, device=DEV, dtype=torch.int64)
+            rc, out = _gemm_gn(xn, wp, bias, M, Cout, 9 * Cin, (1, B, H, W_, Cin, H, W_, 1, 0), splitk, gst, cg, coff, H * W_, lda=Cin)
+            if rc == -4:
+                pytest.skip('tile configuration does not fit this geometry')
+            assert rc == 0, lib.mkd_last_error()
+            sync()
+            res.append((gst, out))
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert torch.equal(res[0][0], res[1][0])
+    assert_close_bf16(res[0][1].float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what=f'conv+gn cfg {cfg}')
+    _check_gstat(res[0][0], res[0][1].view(B, H * W_, Cout), cg, coff, f'conv statistics cfg {cfg}')
