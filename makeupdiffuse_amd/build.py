@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + '.o')
@@ -51,11 +51,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
             cmd = [hipcc] + FLAGS + ['-c', sp, '-o', op]
             if verbose:
                 print('[mkd build]', ' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append((subprocess.Popen(cmd), cmd, stamp, dg))          # translation units compile concurrently (<= 6 of them)
+        objs.append(op)
+    rebuilt = bool(jobs)
+    failed = None
+    for proc, cmd, stamp, dg in jobs:
+        if proc.wait() != 0:
+            failed = failed or cmd
+        else:
             with open(stamp, 'w') as f:
                 f.write(dg)
-            rebuilt = True
-        objs.append(op)
+    if failed:
+        raise subprocess.CalledProcessError(1, failed)
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

@@ -97,8 +97,8 @@ struct Op {
     int cap_sid = -1;       // stream while a hipGraph is being captured (-1: same)
 };
 
-// kinds: [0, 20) conv GEMM by tile config, [20, 40) linear GEMM by tile config, then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 20, K_GROUPNORM = 40, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+// kinds: [0, 32) conv GEMM by tile config, [32, 64) linear GEMM by tile config, then the rest
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 32, K_GROUPNORM = 64, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
@@ -119,9 +119,12 @@ struct mkd_ctx {
     // but measured neutral-to-slower in the pipeline (the consumer inherits the producer's write-back wait that the
     // LayerNorm kernel used to absorb), so it is opt-in: MKD_FUSE_LN=1.
     bool fuse_ln = false;
-    // GroupNorm statistics emitted by the producing kernel's epilogue (deterministic fixed-point atomics) + an element-wise apply
-    // kernel, instead of the two-phase GroupNorm kernel (MKD_GN_FUSED=0: the stand-alone kernel everywhere)
-    bool gn_fused = getenv("MKD_GN_FUSED") ? atoi(getenv("MKD_GN_FUSED")) != 0 : true;
+    // MKD_GN_FUSED=1: GroupNorm statistics emitted by the producing kernel's epilogue (deterministic fixed-point atomics) + an
+    // element-wise apply kernel, instead of the two-phase GroupNorm kernel.  Built, parity-tested - and OFF by default: measured at
+    // batch 8, 256x256 the producers' device-scope atomics cost 0.36 ms per evaluation (6.43 vs 6.18 ms; with the atomics stubbed
+    // out the same plan takes 6.06 ms: DESIGN.md §4.3).
+    bool gn_fused = getenv("MKD_GN_FUSED") ? atoi(getenv("MKD_GN_FUSED")) != 0 : false;
+    bool gn_colstats_only = getenv("MKD_GN_FUSED") && atoi(getenv("MKD_GN_FUSED")) == 2;      // experiment: statistics by a stand-alone kernel after every producer
     Arena gstat; char* gstat_base = nullptr; size_t gstat_cap = 0;
 
     // fused weights (built in finalize)
@@ -575,6 +578,13 @@ struct mkd_ctx {
     void op_gemm(GemmArgs a) {
         a.zero = zero_page;
         a.splitk = 0;
+        if (gn_colstats_only && a.gn_stat) {
+            GnOut g; g.gst = a.gn_stat; g.cg = a.gn_cg; g.coff = a.gn_coff; g.hw = a.gn_hw;
+            a.gn_stat = nullptr;
+            op_gemm(a);
+            op_colstats((const bf16_t*)a.C, a.ldc, a.M / g.hw, g.hw, a.N, g);
+            return;
+        }
         int cfg_i = 0, s = 1;
         if (gemm_resolve(a, &cfg_i, &s)) { cfg_i = 1; s = 1; }       // (an unsupported forced tile fails again, loudly, at launch)
         const size_t need = gemm_ws_bytes(a.M, a.N, s);
@@ -940,8 +950,8 @@ struct mkd_ctx {
         cur_sid = 0;
         if (gn_fused)           // the GroupNorm statistics of this evaluation start from zero (one memset node for all of them)
             push(*cur_plan, [self](hipStream_t st) {
-                if (self->gstat.high) MKD_HIP_CHECK(hipMemsetAsync(self->gstat_base, 0, self->gstat.high, st));
-                return 0;
+                // a kernel, not hipMemsetAsync: as a memset NODE of the captured step graph it costs 1.6 ms per replay (measured)
+                return self->gstat.high ? launch_fill_i64((int64_t*)self->gstat_base, 0, (int)(self->gstat.high / 8), st) : 0;
             }, 1, 0.0, K_MISC, "gn_stat_zero");
         if (has_control) op_edge(0, 1, true, true);      // side stream starts after everything already enqueued by the caller
         cur_sid = 0; ep0 = time_embedding(0);

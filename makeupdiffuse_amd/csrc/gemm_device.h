@@ -39,7 +39,59 @@ constexpr float GN_FIX_SQ = 262144.0f;         // 2^18
 constexpr int GN_GROUPS = 32;
 
 __device__ __forceinline__ void gn_atomic_add(long long* p, long long v) {
+#ifdef MKD_EXP_NO_ATOMIC
+    return;
+#endif
     atomicAdd((unsigned long long*)p, (unsigned long long)v);       // two's complement: wraps correctly for negative sums
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row; fixed order: deterministic
+__device__ __forceinline__ float dpp_row_sum(float v) {
+#define MKD_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    MKD_DPP_ADD(0xB1);       // quad_perm [1,0,3,2]
+    MKD_DPP_ADD(0x4E);       // quad_perm [2,3,0,1]
+    MKD_DPP_ADD(0x141);      // row_half_mirror
+    MKD_DPP_ADD(0x140);      // row_mirror
+#undef MKD_DPP_ADD
+    return v;
+}
+
+// FAST path of the tile statistics, one 16-column fragment at a time: every row of the wave belongs to ONE sample (segment
+// `seg` of the tile), so the lane's sums over the wave's row fragments (cs / cq: its 4 channels of this column fragment) only
+// need a 16-lane row reduction.  All 16 lanes of a row then hold the same 8 totals; lane k < 8 of the row converts total k to
+// fixed point and adds it to the tile's LDS accumulator acc[seg][group] (zeroed at kernel start).  No LDS staging, no barrier.
+// frag_col0: tile column of the fragment's first channel.
+__device__ __forceinline__ void gn_wave_stats(const float (&cs)[4], const float (&cq)[4], int frow, int fq, int frag_col0,
+                                              int valid_cols, int cg, int cfirst, int seg, int ngl, long long* acc) {
+    float tot[8];
+#ifdef MKD_EXP_NO_WAVESTATS
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tot[2 * j] = dpp_row_sum(cs[j]); tot[2 * j + 1] = dpp_row_sum(cq[j]); }
+    float val = tot[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) val = (frow == i) ? tot[i] : val;
+    const int c = frag_col0 + 4 * fq + (frow >> 1);
+    if (frow < 8 && c < valid_cols) {
+        const int gl = (cfirst + c) / cg - cfirst / cg;
+        const long long f = __float2ll_rn(val * ((frow & 1) ? GN_FIX_SQ : GN_FIX_SUM));
+        if (f) gn_atomic_add(acc + (size_t)(seg * ngl + gl) * 2 + (frow & 1), f);
+    }
+}
+
+// ... after a block barrier: one device-scope atomic per (segment, group) entry of the tile's accumulator
+__device__ __forceinline__ void gn_acc_flush(const long long* acc, int nseg, int ngl, int b_first, int g_first, int tid, int nthreads,
+                                             long long* gstat) {
+#ifdef MKD_EXP_NO_FLUSH
+    return;
+#endif
+    for (int i = tid; i < nseg * ngl; i += nthreads) {
+        const long long a = acc[i * 2], q = acc[i * 2 + 1];
+        long long* dst = gstat + ((size_t)(b_first + i / ngl) * GN_GROUPS + g_first + i % ngl) * 2;
+        if (a) gn_atomic_add(dst, a);
+        if (q) gn_atomic_add(dst + 1, q);
+    }
 }
 
 // Column statistics of one output tile that the workgroup has staged in LDS as bf16 [rows][TS] (exactly the values it

@@ -23,7 +23,9 @@ namespace {
 
 using namespace mkdk;
 
-template <int TM, int TN, int WM, int WN, int STAGES, int PP>
+// GNS = 1: the epilogue also accumulates the GroupNorm statistics of the output (gemm_device.h); separate instantiation so that
+// the plain kernel keeps its registers and occupancy
+template <int TM, int TN, int WM, int WN, int STAGES, int PP, int GNS = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
@@ -152,6 +154,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         }
     };
 
+    // GNS: (image, group) accumulator of this tile behind the W ring (GACCB bytes, see the launcher), zeroed here
+    constexpr int GACCB = 4096;
+    long long* const gacc = (long long*)(wring + STAGES * WSB);
+    int g_nseg = 1, g_first = 0, g_ngl = 1;
+    bool gfast = false;
+    if (GNS) {
+        const int vc = min(TN, N - n0);
+        g_nseg = min(IMGS, batch - b0);
+        g_first = (p.gn_coff + n0) / p.gn_cg;
+        g_ngl = (p.gn_coff + n0 + vc - 1) / p.gn_cg - g_first + 1;
+        gfast = ((TH * TW) % (TM / WM)) == 0 && g_nseg * g_ngl <= GACCB / 16;        // every wave's rows lie in one image of the tile
+        if (gfast)
+            for (int i = tid; i < g_nseg * g_ngl * 2; i += 64 * NW) gacc[i] = 0;
+    }
+
     // ---- K loop over (chunk, tap) ------------------------------------------------------------------------------
     const int nch = c_end - c_begin;
     const int nsteps = nch * 9;
@@ -212,17 +229,46 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         }
     }
 
+    if constexpr (GNS != 0) {
+        // ---- epilogue with GroupNorm statistics (as in gemm_kernel; tile row = local pixel index, one segment per image) ----
+        constexpr int GTS = TN + 4;
+        constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
+        constexpr int LDS_MIN = 2 * 4 * NW * 1024 + STAGES * WSB + GACCB;            // smallest patch slot (PP >= 4)
+        static_assert(GTILE + 64 * 16 <= LDS_MIN, "GroupNorm statistics tile must fit in the staging buffers");
+        uint16_t* const gtile = (uint16_t*)smem;
+        if (!gfast) __syncthreads();
+        const int wseg = (wm * (TM / WM)) / (TH * TW);               // image of the tile this wave's rows belong to (fast path)
+        const int vcols = min(TN, N - n0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = mrow[mi];
+                    if (m < 0) continue;
+                    const U16x4 o = epilogue_write_bits(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
+                    if (gfast) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float f = bf16_to_f32(o.v[j]); cs[j] += f; cq[j] += f * f; }
+                    } else {
+                        *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
+                    }
+                }
+            }
+            if (gfast && wseg < g_nseg) gn_wave_stats(cs, cq, frow, fq, wn * (TN / WN) + ni * 16, vcols, p.gn_cg, p.gn_coff + n0, wseg, g_ngl, gacc);
+        }
+        if (gfast) {
+            __syncthreads();
+            gn_acc_flush(gacc, g_nseg, g_ngl, b0, g_first, tid, 64 * NW, p.gn_stat);
+        } else {
+            gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, (batch - b0) * TH * TW), vcols, TH * TW, 0, b0, p.gn_cg, p.gn_coff + n0,
+                          (long long*)(smem + GTILE), (LDS_MIN - GTILE) / 16, p.gn_stat);
+        }
+        return;
+    }
     // ---- epilogue -------------------------------------------------------------------------------------------------
-    // GroupNorm statistics of the output (gemm_device.h): tile row = local pixel index of the spatial tile (image-major), one
-    // segment per image of the tile
-    long long* const gn_stat = p.gn_stat;
-    constexpr int GTS = TN + 4;
-    constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
-    constexpr int LDS_MIN = 2 * 4 * NW * 1024 + STAGES * WSB;            // smallest patch slot (PP >= 4)
-    static_assert(GTILE + 64 * 16 <= LDS_MIN, "GroupNorm statistics tile must fit in the staging buffers");
-    uint16_t* const gtile = (uint16_t*)smem;
-    const bool gns = gn_stat != nullptr && splitk == 1;
-    if (gns) __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mrow[mi];
@@ -232,36 +278,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
             const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
             if (n >= N) continue;
             if (splitk > 1) *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
-            else {
-                const f32x4 val = epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]);
-                if (gns) {
-                    const U16x4 o = epilogue_write_bits(epi, m, n, val);
-                    *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
-                } else {
-                    epilogue_write(epi, m, n, val);
-                }
-            }
+            else epilogue_write(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
         }
     }
-    if (gns)
-        gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, (batch - b0) * TH * TW), min(TN, N - n0), TH * TW, 0, b0, p.gn_cg,
-                      p.gn_coff + n0, (long long*)(smem + GTILE), (LDS_MIN - GTILE) / 16, gn_stat);
 }
 
 template <int TM, int TN, int WM, int WN, int PP>
 int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int STAGES = 3;
     constexpr int NW = WM * WN;
-    const size_t lds = (size_t)2 * PP * NW * 1024 + (size_t)STAGES * TN * 128;
+    const bool gns = a.gn_stat != nullptr && a.splitk == 1;
+    const size_t lds = (size_t)2 * PP * NW * 1024 + (size_t)STAGES * TN * 128 + (gns ? 4096 : 0);      // (+ GroupNorm statistics accumulator)
     if (lds > 160 * 1024) return mkd_fail(-4, "conv3x3_patch: LDS budget exceeded");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[gns]) {
+        hipError_t e = gns ? hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(conv patch LDS): ") + hipGetErrorString(e));
-        attr_set = true;
+        attr_set[gns] = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP>), grid, dim3(64 * NW), lds, stream, a);
+    if (gns) hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 1>), grid, dim3(64 * NW), lds, stream, a);
+    else     hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 0>), grid, dim3(64 * NW), lds, stream, a);
     return 0;
 }
 
@@ -305,7 +342,7 @@ bool conv_patch_supported(const GemmArgs& a, int cfg) {
     const int tm = tms[cfg - 6], tn = tns[cfg - 6], nw = tm == 256 ? 8 : 4;
     int th, tw, im, pp;
     if (!conv_patch_geometry(tm, a.M / (a.Hin * a.Win), a.Hin, a.Win, &th, &tw, &im, &pp, nw)) return false;
-    const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)3 * tn * 128;
+    const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)3 * tn * 128 + (a.gn_stat ? 4096 : 0);
     return lds <= 160 * 1024;
 }
 

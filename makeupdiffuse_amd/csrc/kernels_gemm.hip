@@ -21,6 +21,7 @@
 //     fp32 partial slabs + a fused reduce/epilogue kernel fills the 256 CUs.
 #include "mkd_common.h"
 #include "gemm_device.h"
+#include <algorithm>
 #include <map>
 #include <tuple>
 
@@ -28,8 +29,14 @@ namespace {
 
 using namespace mkdk;
 
-template <int TM, int TN, int WM, int WN, int CONV, int STAGES, int LN = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
+// GNS = 1: the epilogue also accumulates the GroupNorm statistics of the output (gemm_device.h); a separate instantiation, so
+// that the plain kernels keep their register budget (the statistics code costs 10-36 VGPRs and a wave of occupancy)
+// KW > 1: K is ALSO split inside the workgroup: KW groups of WM x WN waves, each with its own LDS ring, take K-steps kg, kg + KW, ...
+// and the partial accumulators are summed through LDS at the end.  The small-M layers have fewer tiles than CUs and their K loop is
+// a chain of (load latency + barrier) steps with one wave per SIMD: KW groups put KW times the bytes in flight on the CU and cut the
+// chain by KW without the second launch and the fp32 slab traffic of split-K over blocks.
+template <int TM, int TN, int WM, int WN, int CONV, int STAGES, int LN = 0, int GNS = 0, int KW = 1>
+__global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XS = TM * 128;          // bytes of one X stage (TM rows x 64 bf16)
     constexpr int WSB = TN * 128;         // bytes of one W stage
@@ -41,6 +48,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     constexpr int MI = TM / WM / 16;      // X fragments (16 rows) per wave
     static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8), "tile/wave layout");
     static_assert(STAGES >= 2 && STAGES <= 6 && 4 * (XP + WP) + (LN ? MI * (LN > 0 ? LN : 1) : 0) < 64, "vmcnt immediates");
+    static_assert(!(LN && GNS), "fused LayerNorm and GroupNorm statistics are separate kernels");
+    static_assert(KW == 1 || (!LN && !GNS), "in-block K split: plain epilogue only");
+    static_assert(KW >= 1 && KW <= 4 && (KW - 1) * TM * TN * 4 <= KW * STAGES * STAGE, "in-block K split: partial tiles are summed in the rings");
     constexpr int LPT = XP + WP;          // global_load_lds per wave per K-tile (exact)
 
     // hoist the argument block into registers (keeps it out of scratch)
@@ -55,7 +65,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int kg = KW > 1 ? (tid >> 6) / NW : 0;              // K group of this wave
+    const int w = KW > 1 ? (tid >> 6) % NW : tid >> 6;        // wave inside its group
+    char* const smg = smem + kg * (STAGES * STAGE);           // this group's ring
     const int wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
@@ -101,10 +113,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     }
 
     auto stage = [&](int buf, int kt) {
-        char* xs = smem + buf * STAGE;
+        char* xs = smg + buf * STAGE;
         char* wsm = xs + XS;
         const int k = kt * BK + sc * 8;
-        const bool kok = k < K;
+        const bool kok = k < K && kt < kt_end;                // (KW > 1: the last round may have no tile for this group)
         int ci = 0, ky = 0, kx = 0;
         if (CONV) {
             const int tap = k / Cin;
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     const int fq = lane >> 4;
 
     auto compute = [&](int buf) {
-        const char* xs = smem + buf * STAGE;
+        const char* xs = smg + buf * STAGE;
         const char* wsm = xs + XS;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -167,18 +179,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 
     const float* const stat_in = p.stat_in; const int stat_in_slots = p.stat_in_slots;
     float* const stat_out = p.stat_out;
-    long long* const gn_stat = p.gn_stat; const int gn_cg = p.gn_cg, gn_coff = p.gn_coff, gn_hw = p.gn_hw;
     constexpr int SL = LN > 0 ? LN : 1;          // LN = 0: off; 1 / 3 / 5: stat loads per lane per row
     float2 lnt[LN ? MI : 1][SL];
 
     // ---- K loop: STAGES-deep LDS ring, STAGES-1 tiles of global_load_lds in flight across each barrier ----
     // Every wave issues exactly LPT loads per tile, in order, so "tile i landed" == "at most LPT * (tiles
     // issued after i) of my loads are still outstanding": a counted s_waitcnt, never a full drain.
-    const int ntile = kt_end - kt_begin;
+    const int ntile = (kt_end - kt_begin + KW - 1) / KW;      // rounds: round i stages K-step kt_begin + i * KW + kg
     // Epilogue operands (bias, residual) are fetched FIRST: older than every tile load, they retire before tile 0 is waited on
     // (vmcnt is in-order, so the counted waits below are unaffected) and their latency hides under the K loop instead of being
     // paid after it - these layers are latency-bound and K is often 5 steps.
-    const bool pre = splitk == 1 && !LN;
+    const bool pre = splitk == 1 && !LN && kg == 0;
+    // GNS: (sample, group) accumulator of this tile behind the ring, zeroed here, long before the epilogue (K-loop barriers between)
+    constexpr int GTAIL = 4096;
+    long long* const gacc = (long long*)(smem + STAGES * STAGE);
+    int g_b_first = 0, g_nseg = 1, g_first = 0, g_ngl = 1;
+    bool gfast = false;
+    if (GNS) {
+        const int vr = min(TM, M - m0), vc = min(TN, N - n0);
+        g_b_first = m0 / p.gn_hw;
+        g_nseg = (m0 + vr - 1) / p.gn_hw - g_b_first + 1;
+        g_first = (p.gn_coff + n0) / p.gn_cg;
+        g_ngl = (p.gn_coff + n0 + vc - 1) / p.gn_cg - g_first + 1;
+        gfast = (p.gn_hw % (TM / WM)) == 0 && g_nseg * g_ngl <= GTAIL / 16;       // every wave's rows lie in one sample
+        if (gfast)
+            for (int i = tid; i < g_nseg * g_ngl * 2; i += 64 * NW) gacc[i] = 0;
+    }
     f32x4 pbias[NI];
     U16x4 pres[NI][MI];
     if (pre) {
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     if (ntile > 0) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
-            if (s < ntile) stage(s, kt_begin + s);
+            if (s < ntile) stage(s, kt_begin + s * KW + kg);
         // fused LayerNorm: row statistics are issued AFTER the prologue tiles and consumed after the loop.  Loads
         // retire in order, so issued earlier they would hold up the first tile wait of every block (their lines
         // were just written by the producer GEMM, possibly through another XCD's L2).  Being younger than tiles
@@ -235,24 +261,80 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
             }
             __builtin_amdgcn_s_barrier();          // tile i visible to all waves; slot of tile i-1 is free
             asm volatile("" ::: "memory");
-            if (i + STAGES - 1 < ntile) stage(nxt, kt_begin + i + STAGES - 1);
+            if (i + STAGES - 1 < ntile) stage(nxt, kt_begin + (i + STAGES - 1) * KW + kg);
             compute(buf);
             buf = (buf + 1 == STAGES) ? 0 : buf + 1;
             nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
         }
     }
 
+    if constexpr (KW > 1) {
+        // ---- sum the K groups' partial tiles: [group - 1][fragment][thread] float4 images in the (now idle) rings ----
+        __syncthreads();
+        f32x4* const red = (f32x4*)smem;
+        const int slot = w * 64 + lane;
+        if (kg > 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) red[((kg - 1) * (NI * MI) + ni * MI + mi) * (NW * 64) + slot] = acc[ni][mi];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KW; ++g)            // fixed order: deterministic
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] += red[((g - 1) * (NI * MI) + ni * MI + mi) * (NW * 64) + slot];
+    }
+    if constexpr (GNS != 0) {
+        // ---- epilogue with GroupNorm statistics (split-K launches use the plain kernel + splitk_epilogue_gn_kernel) ----
+        // Fast path: column-fragment major; per fragment the lane's 4 channels are summed over the wave's row fragments in
+        // registers (8 values), reduced over the 16 lanes of a DPP row and added as fixed-point integers to the tile accumulator.
+        // General path (a wave's rows span several samples): the stored bf16 tile is staged in LDS (the ring is free once every
+        // wave has left the K loop) and reduced by gn_tile_stats.
+        constexpr int GTS = TN + 4;
+        constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
+        static_assert(GTILE + 64 * 16 <= STAGES * STAGE + GTAIL, "GroupNorm statistics tile must fit in the ring");
+        uint16_t* const gtile = (uint16_t*)smem;
+        long long* const gn_stat = p.gn_stat;
+        const int gn_cg = p.gn_cg, gn_coff = p.gn_coff, gn_hw = p.gn_hw;
+        if (!gfast) __syncthreads();
+        const int wrow0 = m0 + wm * (TM / WM);
+        const int wseg = wrow0 / gn_hw - g_b_first;
+        const int vcols = min(TN, N - n0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
+                    if (m >= M) continue;
+                    const U16x4 o = epilogue_write_bits(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
+                    if (gfast) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float f = bf16_to_f32(o.v[j]); cs[j] += f; cq[j] += f * f; }
+                    } else {
+                        *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
+                    }
+                }
+            }
+            if (gfast && wrow0 < M) gn_wave_stats(cs, cq, frow, fq, wn * (TN / WN) + ni * 16, vcols, gn_cg, gn_coff + n0, wseg, g_ngl, gacc);
+        }
+        if (gfast) {
+            __syncthreads();
+            gn_acc_flush(gacc, g_nseg, g_ngl, g_b_first, g_first, tid, 64 * NW, gn_stat);
+        } else {
+            gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, M - m0), vcols, gn_hw, m0 % gn_hw, m0 / gn_hw, gn_cg, gn_coff + n0,
+                          (long long*)(smem + GTILE), (STAGES * STAGE + GTAIL - GTILE) / 16, gn_stat);
+        }
+        return;
+    }
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
     float* const statlds = (float*)(smem + STAGES * STAGE);        // [WN][TM][2] scratch behind the ring
-    // GroupNorm statistics of the output (gemm_device.h): the stored bf16 tile is also staged in LDS (the ring is free once
-    // every wave has left the K loop) and reduced per (sample, group) by gn_tile_stats.
-    constexpr int GTS = TN + 4;                                    // tile row stride in elements (8-byte aligned rows)
-    constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
-    constexpr int LDS_TOTAL = STAGES * STAGE + WN * TM * 2 * 4;
-    static_assert(GTILE + 64 * 16 <= LDS_TOTAL, "GroupNorm statistics tile must fit in the ring");
-    uint16_t* const gtile = (uint16_t*)smem;
-    const bool gns = gn_stat != nullptr && splitk == 1;            // (block-uniform)
-    if (gns) __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
@@ -269,15 +351,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
                     *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
                 } else {
                     const f32x4 v0 = LN ? ln_correct(ln_s, n, acc[ni][mi], mu, rstd) : acc[ni][mi];
-                    const f32x4 val = pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0);
-                    if (gns) {
-                        const U16x4 o = epilogue_write_bits(epi, m, n, val);
-                        *(U16x4*)(gtile + (wm * (TM / WM) + mi * 16 + frow) * GTS + wn * (TN / WN) + ni * 16 + 4 * fq) = o;
-                    } else {
-                        const f32x4 r = epilogue_write(epi, m, n, val);
-                        ps += (r[0] + r[1]) + (r[2] + r[3]);
-                        pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-                    }
+                    const f32x4 r = epilogue_write(epi, m, n, pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0));
+                    ps += (r[0] + r[1]) + (r[2] + r[3]);
+                    pq += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
                 }
             }
         }
@@ -288,9 +364,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
             if (fq == 0) { statlds[(wn * TM + lr) * 2] = ps; statlds[(wn * TM + lr) * 2 + 1] = pq; }
         }
     }
-    if (gns)
-        gn_tile_stats(gtile, GTS, TM, TN, 64 * NW, tid, min(TM, M - m0), min(TN, N - n0), gn_hw, m0 % gn_hw, m0 / gn_hw, gn_cg,
-                      gn_coff + n0, (long long*)(smem + GTILE), (LDS_TOTAL - GTILE) / 16, gn_stat);
     if (stat_out && splitk == 1) {         // one slot per column tile: wave columns summed in a fixed order
         __syncthreads();
         for (int lr = tid; lr < TM; lr += 64 * NW) {
@@ -342,17 +415,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
     }
 }
 
-// split-K reduce + epilogue that also emits the GroupNorm statistics of its output: 16 rows x 256 columns per block, a wave
-// walks 4 consecutive rows (same 4 columns per lane), per-lane sums are flushed when the sample changes, reduced per
-// (sample, group) in LDS (integer adds: order-free) and added to gn_stat with one device-scope atomic per entry.
+// split-K reduce + epilogue that also emits the GroupNorm statistics of its output: same mapping as splitk_epilogue_kernel
+// (4 rows x 256 columns per block, a wave owns one row, a lane 4 columns); the lane's 8 (sum, sumsq) values go to the block's
+// (sample, group) accumulator in LDS as fixed-point integers (order-free), then one device-scope atomic per entry.
 __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs p) {
     constexpr int CAP = 512;
     __shared__ long long acc[CAP * 2];
     const int tid = threadIdx.x;
     const int n = (blockIdx.x * 64 + (tid & 63)) << 2;
-    const int mb = blockIdx.y * 16;
+    const int mb = blockIdx.y * 4;
+    const int m = mb + (tid >> 6);
     const int hw = p.gn_hw, cg = p.gn_cg;
-    const int rows = min(16, p.M - mb);
+    const int rows = min(4, p.M - mb);
     const int b_first = mb / hw;
     const int nseg = (mb + rows - 1) / hw - b_first + 1;
     const int c0 = p.gn_coff + blockIdx.x * 256;                      // consumer-tensor column of this block's first column
@@ -363,61 +437,48 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs 
     if (use_lds)
         for (int i = tid; i < nseg * ngl * 2; i += 256) acc[i] = 0;
     __syncthreads();
-    if (n < p.N) {
+    if (n < p.N && m < p.M) {
         const Epilogue e = make_epilogue(p);
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        U16x4 r4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r4.v[j] = 0;
         if (e.bias) b4 = *(const f32x4*)(e.bias + n);
+        if (e.R) r4 = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
         const size_t slab = (size_t)p.M * p.N;
-        int gl[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gl[j] = (p.gn_coff + n + j) / cg - g_first;
-        float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-        int cur = -1;
-        auto flush = [&]() {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long a = __float2ll_rn(sm[j] * GN_FIX_SUM), q = __float2ll_rn(sq[j] * GN_FIX_SQ);
-                long long* dst = use_lds ? acc + (size_t)((cur - b_first) * ngl + gl[j]) * 2
-                                         : p.gn_stat + ((size_t)cur * GN_GROUPS + g_first + gl[j]) * 2;
-                if (a) gn_atomic_add(dst, a);
-                if (q) gn_atomic_add(dst + 1, q);
-                sm[j] = 0.f; sq[j] = 0.f;
-            }
-        };
-        for (int i = 0; i < 4; ++i) {
-            const int m = mb + (tid >> 6) * 4 + i;
-            if (m >= p.M) break;
-            U16x4 r4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r4.v[j] = 0;
-            if (e.R) r4 = *(const U16x4*)(e.R + (size_t)m * e.ldr + n);
-            const float* src = p.ws + (size_t)m * p.N + n;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int z = 0;
-            for (; z + 4 <= p.splitk; z += 4) {
-                const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
-                const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
-                const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
-                const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
-                v += (a + b) + (c + d);
-            }
-            for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
-            const U16x4 o = epilogue_write_bits(e, m, n, epilogue_value_pre(e, m, n, v, b4, r4));
-            const int b = m / hw;
-            if (b != cur) { if (cur >= 0) flush(); cur = b; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float f = bf16_to_f32(o.v[j]); sm[j] += f; sq[j] += f * f; }
+        const float* src = p.ws + (size_t)m * p.N + n;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= p.splitk; z += 4) {
+            const f32x4 a = *(const f32x4*)(src + (size_t)z * slab);
+            const f32x4 b = *(const f32x4*)(src + (size_t)(z + 1) * slab);
+            const f32x4 c = *(const f32x4*)(src + (size_t)(z + 2) * slab);
+            const f32x4 d = *(const f32x4*)(src + (size_t)(z + 3) * slab);
+            v += (a + b) + (c + d);
         }
-        if (cur >= 0) flush();
+        for (; z < p.splitk; ++z) v += *(const f32x4*)(src + (size_t)z * slab);
+        const U16x4 o = epilogue_write_bits(e, m, n, epilogue_value_pre(e, m, n, v, b4, r4));
+        const int b = m / hw;
+        // channels of one lane fall into at most two groups when cg >= 4: merge what shares a group before the atomics
+        int gl = (p.gn_coff + n) / cg - g_first, left = cg - (p.gn_coff + n - (g_first + gl) * cg);
+        float sm = 0.f, sq = 0.f;
+        auto flush = [&]() {
+            const long long a = __float2ll_rn(sm * GN_FIX_SUM), q = __float2ll_rn(sq * GN_FIX_SQ);
+            long long* dst = use_lds ? acc + (size_t)((b - b_first) * ngl + gl) * 2 : p.gn_stat + ((size_t)b * GN_GROUPS + g_first + gl) * 2;
+            if (a) gn_atomic_add(dst, a);
+            if (q) gn_atomic_add(dst + 1, q);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float f = bf16_to_f32(o.v[j]);
+            sm += f; sq += f * f;
+            if (--left == 0) { flush(); sm = 0.f; sq = 0.f; ++gl; left = cg; }
+        }
+        if (left != cg) flush();
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = tid; i < nseg * ngl; i += 256) {
-            const long long a = acc[i * 2], q = acc[i * 2 + 1];
-            long long* dst = p.gn_stat + ((size_t)(b_first + i / ngl) * GN_GROUPS + g_first + i % ngl) * 2;
-            if (a) gn_atomic_add(dst, a);
-            if (q) gn_atomic_add(dst + 1, q);
-        }
+        gn_acc_flush(acc, nseg, ngl, b_first, g_first, tid, 256, p.gn_stat);
     }
 }
 
@@ -437,12 +498,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs 
 //       instead of 3 x 128 with 17 % of the MFMA work wasted)
 //   17: 32x64, 18: 64x32, 19: 32x32 (4 stages): one CU streams at most ~55 GB/s (tools/micro/stream_rate.hip), so a GEMM with
 //       fewer blocks than CUs finishes sooner when each block pulls FEWER operand bytes ((TM + TN) * K * 2), not more
-constexpr int N_TILE_CFG = 20;
-static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32};
-static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32};
+//   20..29: in-block K split (KW groups of 4 waves, see gemm_kernel): 32x32 x2 / x4, 64x32 x2 / x4, 64x64 x2 / x4, 32x64 x2 / x4,
+//       128x64 x2, 64x128 x2
+constexpr int N_TILE_CFG = 30;
+static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32,
+                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64};
+static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32,
+                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128};
+static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2};
+static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
-                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32"};
+                                                  "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32",
+                                                  "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2"};
 static bool is_patch_cfg(int c) { return c >= 6 && c <= 11; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -562,6 +630,7 @@ static int gemm_resolve_plan(const GemmArgs& a, GemmPlan* out) {
         g.per = (a.K + BK - 1) / BK;
     }
     if (a.stat_out) g = stat_producer_plan(g);
+    if (kTileKW[g.cfg] > 1 && (a.ln_s || a.stat_out || (a.gn_stat && g.splitk == 1))) g.cfg = kTileBase[g.cfg];     // plain epilogue only
     if (is_patch_cfg(g.cfg) && !conv_patch_supported(a, g.cfg)) {
         if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
         g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0, /*pin_cfg=*/1);
@@ -595,9 +664,27 @@ size_t gemm_ws_bytes(int M, int N, int splitk) {
     return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
 }
 
+template <int TM, int TN, int WM, int WN, int STAGES, int KW>
+static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
+    const size_t lds = (size_t)KW * STAGES * (TM * 128 + TN * 128);
+    static bool attr_set[2] = {false, false};
+    if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
+        hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                              : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+        attr_set[a.conv ? 1 : 0] = true;
+    }
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 block(64 * WM * WN * KW);
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
+    return 0;
+}
+
 template <int TM, int TN, int WM, int WN, int STAGES>
 static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
-    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (size_t)WN * TM * 2 * sizeof(float);
+    const bool gns = a.gn_stat != nullptr && splitk == 1;
+    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (gns ? (size_t)4096 : (size_t)WN * TM * 2 * sizeof(float));   // ring + tail
     static bool attr_set[2] = {false, false};
     if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
         hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -607,6 +694,18 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
     }
     dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
     dim3 block(64 * WM * WN);
+    if (gns) {
+        static bool gattr[2] = {false, false};
+        if (lds > 64 * 1024 && !gattr[a.conv ? 1 : 0]) {
+            hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                  : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+            gattr[a.conv ? 1 : 0] = true;
+        }
+        if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 1>), grid, block, lds, stream, a);
+        else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 1>), grid, block, lds, stream, a);
+        return 0;
+    }
     if (a.ln_s) {
         static bool ln_attr = false;
         if (lds > 64 * 1024 && !ln_attr) {
@@ -638,7 +737,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.ln_s && (!a.stat_in || a.stat_in_slots <= 0 || a.stat_in_slots > 20))
         return mkd_fail(-1, "gemm: fused LayerNorm needs the producer's row statistics in 1..20 column slots");
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
-    if (a.gn_stat && (a.act == 2 || a.out_f32 || a.stat_out || a.gn_cg <= 0 || a.gn_hw <= 0 || a.gn_coff < 0 || (a.gn_coff + a.N + a.gn_cg - 1) / a.gn_cg > 32))
+    if (a.gn_stat && (a.act == 2 || a.out_f32 || a.stat_out || a.ln_s || a.gn_cg <= 0 || a.gn_hw <= 0 || a.gn_coff < 0 || (a.gn_coff + a.N + a.gn_cg - 1) / a.gn_cg > 32))
         return mkd_fail(-1, "gemm: GroupNorm statistics need a plain bf16 output, rows per sample, channels per group, <= 32 groups");
     GemmPlan g;
     { const int rc = gemm_resolve_plan(a, &g); if (rc) return rc; }
@@ -664,6 +763,16 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         case 17: rc = launch_tile<32, 64, 2, 2, 4>(a, g.splitk, stream); break;
         case 18: rc = launch_tile<64, 32, 2, 2, 4>(a, g.splitk, stream); break;
         case 19: rc = launch_tile<32, 32, 2, 2, 4>(a, g.splitk, stream); break;
+        case 20: rc = launch_tile_kw<32, 32, 2, 2, 4, 2>(a, g.splitk, stream); break;
+        case 21: rc = launch_tile_kw<32, 32, 2, 2, 4, 4>(a, g.splitk, stream); break;
+        case 22: rc = launch_tile_kw<64, 32, 2, 2, 4, 2>(a, g.splitk, stream); break;
+        case 23: rc = launch_tile_kw<64, 32, 2, 2, 3, 4>(a, g.splitk, stream); break;
+        case 24: rc = launch_tile_kw<64, 64, 2, 2, 4, 2>(a, g.splitk, stream); break;
+        case 25: rc = launch_tile_kw<64, 64, 2, 2, 2, 4>(a, g.splitk, stream); break;
+        case 26: rc = launch_tile_kw<32, 64, 2, 2, 4, 2>(a, g.splitk, stream); break;
+        case 27: rc = launch_tile_kw<32, 64, 2, 2, 3, 4>(a, g.splitk, stream); break;
+        case 28: rc = launch_tile_kw<128, 64, 2, 2, 3, 2>(a, g.splitk, stream); break;
+        case 29: rc = launch_tile_kw<64, 128, 2, 2, 3, 2>(a, g.splitk, stream); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
     }
     if (rc) return rc;
@@ -674,7 +783,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
 
 int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream) {
     if (a.gn_stat) {
-        dim3 rg((a.N / 4 + 63) / 64, (a.M + 15) / 16);
+        dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
         hipLaunchKernelGGL(splitk_epilogue_gn_kernel, rg, dim3(256), 0, stream, a);
         MKD_LAUNCH_CHECK("splitk_epilogue_gn_kernel");
         return 0;

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(320) void gn_apply_stats_kernel(const bf16_t* __res
         double var = (double)q / ((double)GN_FIX_SQ * n) - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         s_mean[tid] = (float)mean;
-        s_rstd[tid] = rsqrtf((float)var + eps);
+        s_rstd[tid] = q ? rsqrtf((float)var + eps) : 1.0f;      // q == 0: an all-zero group, (0 - 0) * rstd = 0 whatever rstd is
     }
     const int v = tid % V, pl = tid / V;
     float pg[8], pb[8];

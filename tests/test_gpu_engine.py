@@ -34,7 +34,7 @@ def small():
     eng = MkdEngine(NetConfig(**SMALL))
     assert set(eng.expected_params()) == set(sd), 'engine and oracle disagree on the state_dict key set'
     eng.load_state_dict(sd)
-    return eng, sd, ocfg, {k: torch.from_numpy(g[k]) for k in g.files if k != 'seed_weights'}
+    return eng, sd, ocfg, {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
 
 
 def test_small_eps_vs_golden(small):
@@ -231,7 +231,7 @@ def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overl
     sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
     eng = MkdEngine(NetConfig(**SMALL))
     eng.load_state_dict(sd)
-    G = {k: torch.from_numpy(g[k]) for k in g.files if k != 'seed_weights'}
+    G = {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
     rep = lambda t: torch.cat([t, t, t[:1]])                      # batch 5: ragged lanes (1+1+1+2 or 2+3)
     for hint, want in ((rep(G['hint']), rep(G['eps'])), (None, rep(G['eps_noctl']))):
         eng.prepare(hint, rep(G['ctx']), latent_hw=(8, 8))
@@ -249,4 +249,36 @@ def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overl
         eng.debug_poison()
         b = eng.sample(rep(G['x']), sch_t, [0.1, 0.3, 0.6, 0.9], [0.3, 0.6, 0.9, 0.99], [0.95, 0.84, 0.63, 0.31], use_graph=True)
         assert torch.isfinite(a).all() and torch.equal(a, b)
+    eng.close()
+
+
+@pytest.mark.parametrize('dec_lanes', [0, 2])
+def test_groupnorm_producer_statistics_plan_matches_golden(dec_lanes, monkeypatch):
+    """MKD_GN_FUSED=1: every GroupNorm reads statistics that the kernels writing its input accumulated (GEMM / LDS-staged conv /
+    split-K epilogues, the copy fallback on the c_concat None path) and only applies them.  Same golden eps, bit-repeatable after
+    NaN-poisoning (integer atomics are order-free), graph replay == eager launches."""
+    monkeypatch.setenv('MKD_GN_FUSED', '1'); monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes))
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.load_state_dict(sd)
+    G = {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
+    rep = lambda t: torch.cat([t, t, t[:1]])
+    for hint, want in ((rep(G['hint']), rep(G['eps'])), (None, rep(G['eps_noctl']))):
+        eng.prepare(hint, rep(G['ctx']), latent_hw=(8, 8))
+        first = None
+        for i in range(3):
+            eng.debug_poison()
+            out = eng.eps(rep(G['x']), rep(G['t']))
+            check_eps(out, want, what=f'fused GroupNorm statistics, lanes {dec_lanes}, rep {i}')
+            first = out if first is None else first
+            assert torch.equal(out, first)
+    sch = sampler.Schedule().make_ddim(5)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    eng.prepare(G['hint'], G['ctx'])
+    a = eng.sample(G['x'], *args, use_graph=False)
+    b = eng.sample(G['x'], *args, use_graph=True)
+    check_eps(a, G['x5'], rel=1.5e-2, cos=0.9999, what='5-step latent, fused GroupNorm statistics')
+    assert torch.equal(a, b)
     eng.close()

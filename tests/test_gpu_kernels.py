@@ -46,8 +46,8 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19])
-@pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1)])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29])
+@pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1), (256, 1280, 1280, 1), (96, 320, 200, 1)])
 def test_gemm_every_tile_config(cfg, M, N, K, splitk):
     """each gather-GEMM tile / pipeline-depth configuration, incl. K not a multiple of 64 and ragged M/N."""
     lib = L()
@@ -145,7 +145,7 @@ def test_gemm_epilogue_variants():
     assert (out[:, N:] == 0).all()
 
 
-@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up', [(2, 16, 16, 64, 320, 1, 0), (1, 8, 8, 128, 160, 1, 1), (2, 12, 20, 32, 96, 2, 0)])
 def test_gemm_conv3x3_160_wide_tiles(cfg, B, H, W_, Cin, Cout, stride, up):
     lib = L()
@@ -458,7 +458,7 @@ def _gemm_gn(A, W, bias, M, N, K, cv, splitk, gst, cg, coff, hw, R=None, ldc=Non
     return rc, out
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 21, 24])
 @pytest.mark.parametrize('B,hw,N,K,cg,coff,splitk', [(3, 64, 320, 320, 10, 0, 1), (2, 256, 640, 192, 30, 320, 1), (5, 16, 1280, 256, 80, 1280, 1),
                                                      (7, 12, 64, 64, 6, 128, 1), (2, 64, 320, 1280, 10, 0, 4)])
 def test_gemm_epilogue_emits_groupnorm_statistics(cfg, B, hw, N, K, cg, coff, splitk):
@@ -488,7 +488,7 @@ def test_gemm_epilogue_emits_groupnorm_statistics(cfg, B, hw, N, K, cg, coff, sp
     assert (res[0][0].cpu()[:, ~used] == 0).all()
 
 
-@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 3, 5])
+@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 3, 5, 25])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,cg,coff,splitk', [(2, 32, 32, 64, 320, 10, 0, 1), (8, 4, 4, 128, 1280, 40, 0, 2), (3, 8, 8, 320, 640, 30, 320, 1),
                                                            (5, 4, 4, 128, 192, 6, 0, 1), (2, 16, 16, 128, 64, 2, 0, 2)])
 def test_conv_epilogue_emits_groupnorm_statistics(cfg, B, H, W_, Cin, Cout, cg, coff, splitk):

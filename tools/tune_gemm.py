@@ -22,8 +22,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 
 DEV = 'cuda:0'
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128]
 POOL_BYTES = 640 << 20
 
 
@@ -161,7 +161,7 @@ def main():
                 continue
         results['_'.join(map(str, shape[:6]))] = {'shape': shape, 'count': count, 'best_cfg': best[0], 'best_splitk': best[1],
                                                   'best_us': best[2], 'default_us': t_def, 'tflops': gf / best[2] * 1e-3,
-                                                  'trials': trials}
+                                                  'n_trials': len(trials)}      # (raw per-trial timings are not kept: only the winner is used)
         total_best += best[2] * count
         total_default += t_def * count
         print(f'[{si + 1}/{len(shapes)}] M={M} N={N} K={K} conv={conv} s={stride} up={up} x{count}: default {t_def:.1f} us -> '
