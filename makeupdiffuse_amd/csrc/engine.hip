@@ -172,7 +172,9 @@ struct mkd_ctx {
     // measured at batch 8, 256x256 (ms per evaluation): no lanes 6.78, 2 decoder lanes 6.58, 4 decoder lanes 6.89, encoder lanes
     // on top +0.25: the encoder phase already runs two nets side by side, a third and fourth stream only add contention
     int dec_lanes = getenv("MKD_DEC_LANES") ? atoi(getenv("MKD_DEC_LANES")) : 2;          // 0 / 2 / 4 half- or quarter-batch decoder lanes
-    bool lane_helpers = getenv("MKD_LANE_HELPERS") ? atoi(getenv("MKD_LANE_HELPERS")) != 0 : false;   // 2 lanes + a helper stream each
+    // 2 lanes + a helper stream each (zero-conv combine / 1x1 skip GEMMs off the lanes' chains): 6.13 vs 6.20 ms per evaluation with the
+    // round-2 tile table (it lost, 6.30 vs 6.01, with round 1's)
+    bool lane_helpers = getenv("MKD_LANE_HELPERS") ? atoi(getenv("MKD_LANE_HELPERS")) != 0 : true;
     int dec_lanes_from = getenv("MKD_DEC_LANES_FROM") ? atoi(getenv("MKD_DEC_LANES_FROM")) : 0;   // deepest blocks as one full-batch chain first
     bool enc_lanes = getenv("MKD_ENC_LANES") ? atoi(getenv("MKD_ENC_LANES")) != 0 : false;
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;

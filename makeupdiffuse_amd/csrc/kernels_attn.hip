@@ -12,10 +12,12 @@
 // operand of O^T += V^T P^T (k-order permuted identically in both operands) - P never touches LDS.
 // Head dims 40 / 80 / 160 are zero-padded to the 32-deep MFMA K step inside LDS only.
 #include "mkd_common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int KT = 64;            // keys per tile
+// keys per tile: 64 (self-attention streams tiles with an online softmax) or 96 (KT template parameter): the 77 context keys of
+// the cross-attention then fit ONE tile - no second, 80 %-masked tile, no rescale of O, one barrier pair instead of two.
 // MKD_ATTN_TAIL=1 sends the last 8 / 16 channels of dh = 40 / 80 through one 16-deep MFMA (40 padded to 48, not 64).  In the
 // 8-wave build (accumulators in VGPRs) a 16x16x16 result feeding a 16x16x32 SrcC, or the reverse, was read too early
 // (sporadically wrong scores; the 4-wave build keeps them in AGPRs and is right); with 32 explicit wait states it is correct
@@ -24,7 +26,7 @@ constexpr int KT = 64;            // keys per tile
 #define MKD_ATTN_TAIL 0
 #endif
 
-template <int DH>
+template <int DH, int KT>
 struct AttnCfg {
     static constexpr int TAIL = (MKD_ATTN_TAIL && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
     static constexpr int KS = TAIL ? DH / 32 : (DH + 31) / 32;          // 32-deep k-steps of QK^T
@@ -44,14 +46,16 @@ struct AttnCfg {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-template <int DH, int NW>
+template <int DH, int NW, int KT>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                         const bf16_t* __restrict__ K, int ldk,
                                                         const bf16_t* __restrict__ V, int ldv,
                                                         bf16_t* __restrict__ O, int ldo,
                                                         int Tq, int Tk, int heads, float scale_log2e, int causal) {
-    using C = AttnCfg<DH>;
-    __shared__ __attribute__((aligned(16))) char smem[C::KBYTES + C::VBYTES];
+    using C = AttnCfg<DH, KT>;
+    static_assert(KT % 32 == 0, "key tile: whole 32-key PV steps");
+    constexpr int KB = KT / 16;          // 16-key blocks of S^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // C::KBYTES + C::VBYTES (66 KB for dh 160 with 96-key tiles)
     char* ks = smem;
     char* vs = smem + C::KBYTES;
 
@@ -144,10 +148,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
         __syncthreads();
         if (t + 1 < ntiles) prefetch(key0 + KT);           // in flight while this tile is consumed
 
-        // ---- S^T[key][q] for 4 key blocks of 16 -------------------------------------------------
-        f32x4 st[4];
+        // ---- S^T[key][q] for KB key blocks of 16 ------------------------------------------------
+        f32x4 st[KB];
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
+        for (int mf = 0; mf < KB; ++mf) {
             st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             const char* krow = ks + (16 * mf + qc) * C::KROW;
             if (C::TAIL) {                   // the 16-deep step first: the 32-deep steps then accumulate on its result
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
         float mx = -INFINITY;
         if (causal || key0 + KT > Tk) {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+            for (int mf = 0; mf < KB; ++mf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = key0 + 16 * mf + 4 * g + r;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
                 }
         } else {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+            for (int mf = 0; mf < KB; ++mf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
         }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
         const float m_new = fmaxf(m_run, mx * scale_log2e);   // finite: the first tile always holds a visible key
         float psum = 0.f;
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int mf = 0; mf < KB; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mf][r], scale_log2e, -m_new));
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 
         // ---- O^T[d][q] += V^T[d][key'] P^T[key'][q]; key'(g, j) = 32*s + (j<4 ? 4g+j : 16+4g+j-4) -----
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KT / 32; ++s) {
             bf16x8 pf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -255,14 +259,27 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
     const float sl = scale * 1.4426950408889634f;
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
+    static const bool kt96 = !(getenv("MKD_ATTN_KT96") && atoi(getenv("MKD_ATTN_KT96")) == 0);      // (A/B knob)
+    const bool one96 = kt96 && !wide && !causal && Tk > 64 && Tk <= 96;      // cross-attention (77 context keys): one 96-key tile
     const int qb = wide ? 128 : 64;
     dim3 grid((Tq + qb - 1) / qb, batch * heads);
+#define MKD_ATTN_LAUNCH(D, NWV, KTV)                                                                          \
+    do {                                                                                                      \
+        constexpr int lds = AttnCfg<D, KTV>::KBYTES + AttnCfg<D, KTV>::VBYTES;                                  \
+        static bool attr = false;                                                                             \
+        if (lds > 64 * 1024 && !attr) {                                                                       \
+            hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<D, NWV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(attention LDS): ") + hipGetErrorString(e));            \
+            attr = true;                                                                                      \
+        }                                                                                                     \
+        hipLaunchKernelGGL((attention_kernel<D, NWV, KTV>), grid, dim3(64 * NWV), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,     \
+                           heads, sl, causal);                                                                \
+    } while (0)
 #define MKD_ATTN_CASE(D)                                                                                      \
     case D:                                                                                                   \
-        if (wide) hipLaunchKernelGGL((attention_kernel<D, 8>), grid, dim3(512), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo, \
-                                     Tq, Tk, heads, sl, causal);                                              \
-        else hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, o, ldo,      \
-                                Tq, Tk, heads, sl, causal);                                                   \
+        if (wide) MKD_ATTN_LAUNCH(D, 8, 64);                                                                  \
+        else if (one96) MKD_ATTN_LAUNCH(D, 4, 96);                                                            \
+        else MKD_ATTN_LAUNCH(D, 4, 64);                                                                       \
         break;
     switch (dh) {
         MKD_ATTN_CASE(8)
@@ -276,6 +293,7 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
             return mkd_fail(-4, "attention: unsupported head dim " + std::to_string(dh));
     }
 #undef MKD_ATTN_CASE
+#undef MKD_ATTN_LAUNCH
     MKD_LAUNCH_CHECK("attention_kernel");
     return 0;
 }

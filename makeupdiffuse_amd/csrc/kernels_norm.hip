@@ -8,6 +8,7 @@
 // (2) fold partials -> mean/rstd, apply gamma/beta (+SiLU), 16-B stores.
 // LayerNorm: one 64-lane wavefront per row, row kept in registers, wave-shuffle reductions.
 #include "mkd_common.h"
+#include <cstdlib>
 #include "gemm_device.h"
 
 namespace {
@@ -527,7 +528,8 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
         if (gpb <= groups) {
             const int nch = gpb * cg;
             const size_t slab = (size_t)hw * nch * sizeof(bf16_t);
-            if (nch / 8 <= 256 && slab <= (size_t)384 * 1024) {   // (V <= 256 <= blockDim)
+            static const int two_kernel_min_hw = getenv("MKD_GN_2K_MINHW") ? atoi(getenv("MKD_GN_2K_MINHW")) : (1 << 30);    // (A/B knob)
+            if (nch / 8 <= 256 && slab <= (size_t)384 * 1024 && hw < two_kernel_min_hw) {   // (V <= 256 <= blockDim)
                 // smallest block (256..1024 threads) whose threads hold their whole share in <= 16 registers-vectors
                 const int V = nch / 8;
                 // 256 / 512 threads with <= 16 vectors per thread, or 1024 threads with <= 8 (register budget);

@@ -219,13 +219,13 @@ def test_full_size_eps_vs_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize('dec_lanes,enc_lanes,overlap', [(0, 0, 1), (0, 0, 0), (2, 0, 1), (4, 0, 1), (2, 1, 1), (4, 1, 1)])
-def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overlap, monkeypatch):
+@pytest.mark.parametrize('dec_lanes,enc_lanes,overlap,helpers', [(0, 0, 1, 0), (0, 0, 0, 0), (2, 0, 1, 0), (2, 0, 1, 1), (4, 0, 1, 0), (2, 1, 1, 1), (4, 1, 1, 0)])
+def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overlap, helpers, monkeypatch):
     """Every multi-stream configuration (decoder helpers on the side stream, half-/quarter-batch decoder lanes, half-batch
     encoder lanes): NaN-poison all buffers an evaluation produces, evaluate, and require the golden result, bit-identical
     across repetitions - a kernel that runs ahead of its producer would read NaN instead of the previous call's values."""
     monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes)); monkeypatch.setenv('MKD_ENC_LANES', str(enc_lanes))
-    monkeypatch.setenv('MKD_DEC_OVERLAP', str(overlap))
+    monkeypatch.setenv('MKD_DEC_OVERLAP', str(overlap)); monkeypatch.setenv('MKD_LANE_HELPERS', str(helpers))
     g = np.load(os.path.join(GOLD, 'small_eps.npz'))
     ocfg = nets.NetConfig(**SMALL)
     sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
