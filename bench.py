@@ -56,7 +56,7 @@ def pmc_traffic_bytes_per_launch(kernel_fn):
     None when the summaries are absent.  (PMC cannot be collected from inside this process.)"""
     import csv
     tot = {}
-    for name, mult in (('r1_pmc_fetch_size_kb.csv', 2.0), ('r1_pmc_write_size_kb.csv', 1.0)):
+    for name, mult in (('r2_pmc_fetch_size_kb.csv', 2.0), ('r2_pmc_write_size_kb.csv', 1.0)):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             return None

@@ -222,6 +222,17 @@ int mkd_gemm_gnstat_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw,
 int mkd_gn_colstats(const uint16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, int64_t* gstat, void* stream);
 int mkd_gn_apply_stats(const uint16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, uint16_t* y,
                        int ld_out, int batch, int hw, int C, const int64_t* gstat, void* stream);
+/* A split-K GEMM / conv3x3 whose output feeds a GroupNorm(32) [+SiLU]: the GEMM leaves its fp32 partial slabs and ONE kernel does
+ * slab reduction + GEMM epilogue (bias, per-sample row bias, scale, residual, bf16 rounding) + GroupNorm -> y; the raw GEMM output
+ * is also written to C when write_raw != 0 (C must then be valid).  Same arguments as mkd_gemm_bf16 (act must be 0, bf16 output,
+ * rows_per_batch = rows per sample when rowbias is given).  Returns -4 when this shape would not be split over K (splitk = 0 picks
+ * the tuned value) or the GroupNorm geometry does not fit the single-pass kernel: call mkd_gemm_bf16 + mkd_groupnorm then. */
+int mkd_gemm_groupnorm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                            const float* rowbias, int ldrb, int rows_per_batch,
+                            const uint16_t* R, int ldr, float scale, void* C, int ldc, int write_raw, int M, int N, int K,
+                            int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
+                            int stride, int upsample, int splitk, int rows_per_sample,
+                            const float* gamma, const float* beta, float eps, int silu, uint16_t* y, int ld_y, void* stream);
 /* LayerNorm over the last dim of [rows, d] bf16. */
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
                   uint16_t* y, int rows, int d, void* stream);

@@ -612,8 +612,11 @@ struct mkd_ctx {
         a.gn_stat = e.gn.gst; a.gn_cg = e.gn.cg; a.gn_coff = e.gn.coff; a.gn_hw = e.gn.hw;
         op_gemm(a);
     }
-    // 3x3 conv, pad 1; returns output spatial dims through Hout/Wout
+    // 3x3 conv, pad 1
     void op_conv(const Tensor& in, const bf16_t* W, int N, int stride, int up, const Epi& e, bf16_t* C, int ldc) {
+        op_gemm(conv_args(in, W, N, stride, up, e, C, ldc));
+    }
+    GemmArgs conv_args(const Tensor& in, const bf16_t* W, int N, int stride, int up, const Epi& e, bf16_t* C, int ldc) {
         GemmArgs a; memset(&a, 0, sizeof(a));
         const int Hs = in.H << up, Ws = in.W << up;
         const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
@@ -622,7 +625,33 @@ struct mkd_ctx {
         a.C = C; a.ldc = ldc; a.out_f32 = 0; a.M = in.B * Ho * Wo; a.N = N; a.K = 9 * in.C; a.conv = 1;
         a.Hin = in.H; a.Win = in.W; a.Cin = in.C; a.Hout = Ho; a.Wout = Wo; a.stride = stride; a.up = up;
         a.gn_stat = e.gn.gst; a.gn_cg = e.gn.cg; a.gn_coff = e.gn.coff; a.gn_hw = e.gn.hw;
-        op_gemm(a);
+        return a;
+    }
+    // A split-K GEMM whose output is read by a GroupNorm: instead of [GEMM -> partial slabs][reduce + epilogue -> tensor][GroupNorm]
+    // emit [GEMM -> partial slabs][one kernel: reduce + epilogue + GroupNorm (+ the raw tensor when `raw` says it is needed)].
+    // Returns false (nothing emitted) when the GEMM of this shape is not split or the geometry does not fit: the caller then
+    // emits the separate ops.  MKD_GN_SLAB=0 turns it off; MKD_GN_SLAB_MINC: only for at least this many channels.  Measured at batch
+    // 8, 256x256 (ms per evaluation): off 6.12, all ResBlocks 6.14 (40 launches fewer, but with C = 320 / 640 the GroupNorm grid of
+    // 64 / 128 workgroups reads 31 MB of slabs slower than the full-chip reduce kernel), C >= 1280 only 6.10 -> default 1280.
+    bool gn_slab = getenv("MKD_GN_SLAB") ? atoi(getenv("MKD_GN_SLAB")) != 0 : true;
+    int gn_slab_minc = getenv("MKD_GN_SLAB_MINC") ? atoi(getenv("MKD_GN_SLAB_MINC")) : 1280;
+    bool op_gemm_then_gn(GemmArgs a, bool raw, int nb, int hw, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_y) {
+        if (!gn_slab || a.gn_stat || a.N < gn_slab_minc || !gn_from_slabs_supported(nb, hw, a.N) || a.M != nb * hw) return false;
+        a.zero = zero_page; a.splitk = 0;
+        int cfg_i = 0, sk = 1;
+        if (gemm_resolve(a, &cfg_i, &sk) || sk < 2) return false;
+        a.defer_epilogue = 1;
+        op_gemm(a);                                   // (counts 2 launches for a split GEMM: corrected below)
+        if (counting_eps) --launches_eps;
+        if (!dry) cur_plan->back().launches = 1;
+        mkd_ctx* self = this;
+        const int sid = cur_sid;
+        push(*cur_plan, [self, a, sid, sk, raw, nb, hw, gamma, beta, eps, silu, y, ld_y](hipStream_t st) {
+            GemmArgs b = a; b.ws = self->splitk_ws[arena_of(sid)]; b.splitk = sk;
+            if (!raw) b.C = nullptr;
+            return launch_gn_from_slabs(b, gamma, beta, eps, silu, y, ld_y, nb, hw, st);
+        }, 1, 0.0, K_GROUPNORM, "slab B=" + std::to_string(nb) + " HW=" + std::to_string(hw) + " C=" + std::to_string(a.N) + " splitk=" + std::to_string(sk));
+        return true;
     }
     void op_gn(const Tensor& in, const float* gamma, const float* beta, float eps, int silu, bf16_t* out, int ld_out) {
         if (in.gst) {          // statistics were accumulated by the producers of `in`: element-wise apply
@@ -680,9 +709,13 @@ struct mkd_ctx {
         Tensor t2 = talloc(TA(), x.B, x.H, x.W, cout);
         want_stats(t2);
         Epi e1; e1.bias = wf(p + ".in_layers.2.bias"); e1.rowbias = embproj + emb_off.at(p); e1.ldrb = ld_emb; e1.rpb = hw; e1.gn = gn_of(t2);
-        op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
         Tensor t3 = talloc(TA(), x.B, x.H, x.W, cout);
-        op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
+        // conv1 -> GroupNorm -> conv2: nothing else reads conv1's output, so a split conv1 feeds the GroupNorm straight from its slabs
+        if (!op_gemm_then_gn(conv_args(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld), /*raw=*/false, x.B, hw,
+                             wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld)) {
+            op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
+            op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
+        }
         Epi e2; e2.bias = wf(p + ".out_layers.3.bias"); e2.gn = go;
         if (x.C != cout && side_skip) {
             op_edge(helper_stream, lane_main);           // the lane waits for the skip GEMM
@@ -1948,6 +1981,38 @@ int mkd_gemm_gnstat_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw,
     if (!gn_stat) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_gnstat_bf16: null statistics buffer");
     return gemm_entry(A, lda, W, ldw, bias, rowbias, ldrb, rows_per_batch, R, ldr, scale, act, C, ldc, out_f32, M, N, K, conv3x3, batch,
                       Hin, Win, Cin, Hout, Wout, stride, up, splitk, (long long*)gn_stat, gn_cg, gn_coff, gn_hw, stream);
+}
+int mkd_gemm_groupnorm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
+                            int rows_per_batch, const uint16_t* R, int ldr, float scale, void* C, int ldc, int write_raw, int M, int N,
+                            int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up, int splitk,
+                            int rows_per_sample, const float* gamma, const float* beta, float eps, int silu, uint16_t* y, int ld_y,
+                            void* stream) {
+    if (!A || !W || !C || !gamma || !beta || !y) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: null pointer");
+    if (rows_per_sample <= 0 || M % rows_per_sample) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: M must be a multiple of rows_per_sample");
+    if (!g_zero) {
+        MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
+        MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));
+    }
+    if (conv3x3 && M != batch * Hout * Wout) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: M != batch*Hout*Wout");
+    const int nb = M / rows_per_sample;
+    if (!gn_from_slabs_supported(nb, rows_per_sample, N)) return mkd_fail(MKD_ERR_UNSUPPORTED, "mkd_gemm_groupnorm_bf16: GroupNorm geometry does not fit the single-pass kernel");
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = bias; a.rowbias = rowbias; a.ldrb = ldrb; a.rows_per_batch = rows_per_batch;
+    a.R = R; a.ldr = ldr; a.scale = scale; a.act = 0; a.C = C; a.ldc = ldc; a.out_f32 = 0; a.M = M; a.N = N; a.K = K;
+    a.conv = conv3x3 ? 1 : 0; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
+    a.zero = g_zero; a.splitk = splitk > 0 ? splitk : 0;
+    int cfg_i = 0, s = 1;
+    int rc = gemm_resolve(a, &cfg_i, &s);
+    if (rc) return rc;
+    if (s < 2) return mkd_fail(MKD_ERR_UNSUPPORTED, "mkd_gemm_groupnorm_bf16: this shape is not split over K");
+    rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(M, N, s));
+    if (rc) return rc;
+    a.ws = g_ws; a.ws_bytes = g_ws_bytes; a.defer_epilogue = 1;
+    rc = launch_gemm(a, (hipStream_t)stream);
+    if (rc) return rc;
+    a.splitk = s;
+    if (!write_raw) a.C = nullptr;
+    return launch_gn_from_slabs(a, gamma, beta, eps, silu, y, ld_y, nb, rows_per_sample, (hipStream_t)stream);
 }
 int mkd_gn_colstats(const uint16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, int64_t* gstat, void* stream) {
     if (!x || !gstat) return mkd_fail(MKD_ERR_ARG, "mkd_gn_colstats: null pointer");

@@ -376,6 +376,6 @@ int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
     }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("conv3x3_patch_kernel");
-    if (s > 1) return launch_splitk_epilogue(a, stream);
+    if (s > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream);
     return 0;
 }

@@ -777,7 +777,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("gemm_kernel");
-    if (g.splitk > 1) return launch_splitk_epilogue(a, stream);
+    if (g.splitk > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream);
     return 0;
 }
 

@@ -295,6 +295,143 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const b
     }
 }
 
+// GroupNorm [+SiLU] fed by the fp32 partial slabs of a split-K GEMM (launch_gemm with defer_epilogue): the workgroup of (sample,
+// group chunk) sums the slabs of ITS rows and channels, applies the GEMM epilogue (bias, per-sample row bias, scale, residual) and
+// rounds to bf16 exactly as splitk_epilogue_kernel would - the values stay in registers (NV vectors per thread), optionally go to
+// memory (raw != null), then statistics and normalisation as in gn_fused_kernel.  Replaces two dependent launches (split-K reduce,
+// GroupNorm) and the round trip of the intermediate tensor by one.
+struct SlabGn {
+    const float* ws; int splitk; int M; int N;
+    const float* bias; const float* rowbias; int ldrb; int rpb; float scale; const bf16_t* R; int ldr;
+    bf16_t* raw; int ldraw;
+};
+
+template <int NV>
+__global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_slab_kernel(const SlabGn a, bf16_t* __restrict__ y, int ld_out,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       float eps, int silu, int hw, int C, int groups, int gpb) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];
+    const int cg = C / groups;
+    const int nch = gpb * cg;                 // channels of this block (multiple of 8, cg >= 8: launcher)
+    const int V = nch >> 3;
+    const int NT = blockDim.x;
+    const int P = NT / V;
+    const int T = V * P;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * nch;
+    const bool active = tid < T;
+    const int v = active ? tid % V : 0;
+    const int pl = active ? tid / V : 0;
+    const int n = c0 + v * 8;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
+    U16x8 keep[NV];
+    float pg[8], pb[8];
+    if (active) {
+        // epilogue operands of this thread's 8 channels (applied in splitk_epilogue_kernel's order: results are bit-identical to
+        // the two-kernel path)
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f}, rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) { e0 = *(const f32x4*)(a.bias + n); e1 = *(const f32x4*)(a.bias + n + 4); }
+        if (a.rowbias) {
+            const float* rb = a.rowbias + (size_t)(((size_t)b * hw) / a.rpb) * a.ldrb + n;      // one row bias per sample (rpb == hw)
+            rb0 = *(const f32x4*)rb; rb1 = *(const f32x4*)(rb + 4);
+        }
+        const f32x4 g0 = *(const f32x4*)(gamma + n), g1 = *(const f32x4*)(gamma + n + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + n), b1 = *(const f32x4*)(beta + n + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[j] = g0[j]; pg[4 + j] = g1[j]; pb[j] = b0[j]; pb[4 + j] = b1[j]; }
+        const size_t slab = (size_t)a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int r = pl + i * P;
+            if (r < hw) {
+                const size_t m = (size_t)b * hw + r;
+                const float* src = a.ws + m * a.N + n;
+                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                int z = 0;
+                for (; z + 4 <= a.splitk; z += 4) {           // slabs summed 4 at a time, as splitk_epilogue_kernel does
+                    const float* s0 = src + (size_t)z * slab;
+                    lo += (*(const f32x4*)s0 + *(const f32x4*)(s0 + slab)) + (*(const f32x4*)(s0 + 2 * slab) + *(const f32x4*)(s0 + 3 * slab));
+                    hi += (*(const f32x4*)(s0 + 4) + *(const f32x4*)(s0 + slab + 4)) + (*(const f32x4*)(s0 + 2 * slab + 4) + *(const f32x4*)(s0 + 3 * slab + 4));
+                }
+                for (; z < a.splitk; ++z) { lo += *(const f32x4*)(src + (size_t)z * slab); hi += *(const f32x4*)(src + (size_t)z * slab + 4); }
+                lo += e0; hi += e1;
+                if (a.rowbias) { lo += rb0; hi += rb1; }
+                lo *= a.scale; hi *= a.scale;
+                if (a.R) {
+                    const U16x8 rr = *(const U16x8*)(a.R + m * a.ldr + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { lo[j] += bf16_to_f32(rr.v[j]); hi[j] += bf16_to_f32(rr.v[4 + j]); }
+                }
+                U16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o.v[j] = f32_to_bf16(lo[j]); o.v[4 + j] = f32_to_bf16(hi[j]); }
+                keep[i] = o;
+                if (a.raw) *(U16x8*)(a.raw + m * a.ldraw + n) = o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(o.v[j]); sum[j] += f; sq[j] += f * f; }
+            }
+        }
+    }
+    float* gstat = s_red + 2 * (NT >> 6) * gpb;          // [gpb][2] mean, rstd (after the per-wave partials)
+    {   // group statistics straight from the registers (cg >= 8): as gn_fused_kernel
+        const int gA = (v * 8) / cg;
+        const int split = min(8, (gA + 1) * cg - v * 8);
+        float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < split) { a0 += sum[j]; q0 += sq[j]; } else { a1 += sum[j]; q1 += sq[j]; }
+            }
+        }
+        const int nw = NT >> 6, wv = tid >> 6;
+        for (int g = 0; g < gpb; ++g) {
+            float sg = (gA == g ? a0 : 0.f) + (gA + 1 == g ? a1 : 0.f);
+            float qg = (gA == g ? q0 : 0.f) + (gA + 1 == g ? q1 : 0.f);
+            sg = wave_sum(sg); qg = wave_sum(qg);
+            if ((tid & 63) == 0) { s_red[(wv * gpb + g) * 2] = sg; s_red[(wv * gpb + g) * 2 + 1] = qg; }
+        }
+        __syncthreads();
+        if (tid < gpb) {
+            float s = 0.f, q = 0.f;
+            for (int k = 0; k < nw; ++k) { s += s_red[(k * gpb + tid) * 2]; q += s_red[(k * gpb + tid) * 2 + 1]; }
+            const float cnt = (float)hw * (float)cg;
+            const float mean = s / cnt;
+            float var = q / cnt - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            gstat[tid * 2] = mean;
+            gstat[tid * 2 + 1] = rsqrtf(var + eps);
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (v * 8 + j) / cg;
+        const float sc = pg[j] * gstat[g * 2 + 1];
+        sa[j] = sc;
+        sb[j] = pb[j] - gstat[g * 2] * sc;
+    }
+    bf16_t* yout = y + (size_t)b * hw * ld_out + n;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int r = pl + i * P;
+        if (r < hw) {
+            U16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = bf16_to_f32(keep[i].v[j]) * sa[j] + sb[j];
+                if (silu) f = silu_f(f);
+                o.v[j] = f32_to_bf16(f);
+            }
+            *(U16x8*)(yout + (size_t)r * ld_out) = o;
+        }
+    }
+}
+
 // GroupNorm APPLY with statistics that the producers of x already accumulated (gemm_device.h: gstat[sample][32][2], 64-bit
 // fixed point): no reduction, no dependency between workgroups - a plain element-wise kernel over (sample, row chunk) that
 // fills the chip.  threads = V * P, V = C / 8 vectors per pixel (a thread keeps its 8 channels: scale / shift in registers).
@@ -568,6 +705,52 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
                        hw, C, groups, rows_per_chunk, nchunks, partials);
     MKD_LAUNCH_CHECK("gn_apply_kernel");
+    return 0;
+}
+
+// geometry of the slab-fed kernel: group chunk with a channel span that is a multiple of 8, at most 16 vectors per thread
+static bool gn_slab_shape(int hw, int C, int* gpb_out, int* nt_out, int* per_out) {
+    const int groups = 32;
+    if (C % groups) return false;
+    const int cg = C / groups;
+    if (cg < 8) return false;                                   // (register statistics path; smaller groups keep the two kernels)
+    int gpb = 1;
+    while (gpb <= groups && ((gpb * cg) % 8 || groups % gpb)) ++gpb;
+    if (gpb > groups) return false;
+    const int V = gpb * cg / 8;
+    if (V > 256) return false;
+    auto per_of = [&](int t) { const int P = t / V; return (hw + P - 1) / P; };
+    int nt, per;
+    if (per_of(256) <= 16) { nt = 256; per = per_of(256); }
+    else if (per_of(512) <= 16) { nt = 512; per = per_of(512); }
+    else if (per_of(1024) <= 8) { nt = 1024; per = per_of(1024); }
+    else return false;
+    *gpb_out = gpb; *nt_out = nt; *per_out = per;
+    return true;
+}
+bool gn_from_slabs_supported(int batch, int hw, int C) {
+    int gpb, nt, per;
+    return batch > 0 && C % 8 == 0 && gn_slab_shape(hw, C, &gpb, &nt, &per);
+}
+
+int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
+                         int batch, int hw, hipStream_t stream) {
+    int gpb, nt, per;
+    if (!gn_slab_shape(hw, a.N, &gpb, &nt, &per)) return mkd_fail(-4, "gn_from_slabs: geometry does not fit the single-pass kernel");
+    if (a.splitk < 2 || !a.ws || a.M != batch * hw || a.N % 8 || ld_out % 8 || a.out_f32 || a.act != 0 || (a.R && a.ldr % 8) ||
+        (a.C && a.ldc % 8) || (a.rowbias && a.rows_per_batch != hw))
+        return mkd_fail(-1, "gn_from_slabs: needs split-K slabs of a plain bf16 GEMM with one row bias per sample");
+    SlabGn sg;
+    sg.ws = a.ws; sg.splitk = a.splitk; sg.M = a.M; sg.N = a.N; sg.bias = a.bias; sg.rowbias = a.rowbias; sg.ldrb = a.ldrb;
+    sg.rpb = a.rows_per_batch > 0 ? a.rows_per_batch : 1; sg.scale = a.scale; sg.R = a.R; sg.ldr = a.ldr; sg.raw = (bf16_t*)a.C; sg.ldraw = a.ldc;
+    const size_t lds = (size_t)(2 * (nt / 64) * gpb + 2 * gpb) * sizeof(float);
+    dim3 grid(32 / gpb, batch);
+#define MKD_GNS_LAUNCH(NVV) hipLaunchKernelGGL(gn_slab_kernel<NVV>, grid, dim3(nt), lds, stream, sg, y, ld_out, gamma, beta, eps, silu, hw, a.N, 32, gpb)
+    if (per <= 4) MKD_GNS_LAUNCH(4);
+    else if (per <= 8) MKD_GNS_LAUNCH(8);
+    else MKD_GNS_LAUNCH(16);
+#undef MKD_GNS_LAUNCH
+    MKD_LAUNCH_CHECK("gn_slab_kernel");
     return 0;
 }
 

@@ -85,6 +85,7 @@ struct GemmArgs {
     // GroupNorm statistics of the tensor this GEMM writes (part of): gn_stat[sample][32][2] int64 fixed point (gemm_device.h);
     // gn_cg channels per group OF THE CONSUMER's tensor, gn_coff = column of this output inside it (concat halves), gn_hw rows per sample
     long long* gn_stat; int gn_cg; int gn_coff; int gn_hw;
+    int defer_epilogue;                     // split-K launches: leave the fp32 partial slabs in ws; the caller's next kernel reduces them (launch_gn_from_slabs)
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
@@ -122,6 +123,13 @@ size_t groupnorm_partials_bytes(int batch, int hw, int groups);
 // and the stand-alone producer of the same statistics for tensors whose writer cannot emit them
 int launch_gn_apply_stats(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
                           int batch, int hw, int C, const long long* gstat, hipStream_t stream);
+// GroupNorm [+SiLU] of a split-K GEMM's output straight from its fp32 partial slabs (launched with defer_epilogue): one kernel
+// does the slab reduction, the GEMM epilogue (bias, row bias, scale, residual, bf16 rounding) and the normalisation; the raw
+// output is also stored when a.C is non-null.  a = the GEMM's arguments with ws / splitk as launch_gemm resolved them.
+// Returns -4 when the geometry does not fit the single-pass kernel (the caller then runs the two kernels separately).
+int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
+                         int batch, int hw, hipStream_t stream);
+bool gn_from_slabs_supported(int batch, int hw, int C);
 int launch_gn_colstats(const bf16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, long long* gstat, hipStream_t stream);
 int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
                           bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream);

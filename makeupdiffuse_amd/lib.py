@@ -75,6 +75,8 @@ SIGNATURES = {
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mkd_gemm_gnstat_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                                   _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    'mkd_gemm_groupnorm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I,
+                                     _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _I, _P, _I, _P]),
     'mkd_gn_colstats': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mkd_gn_apply_stats': (_I, [_P, _I, _P, _P, _F, _I, _P, _I, _I, _I, _I, _P, _P]),
     'mkd_gemm_force_tile': (_I, [_I]),

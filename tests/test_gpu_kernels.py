@@ -521,3 +521,56 @@ def test_conv_epilogue_emits_groupnorm_statistics(cfg, B, H, W_, Cin, Cout, cg, 
     assert torch.equal(res[0][0], res[1][0])
     assert_close_bf16(res[0][1].float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what=f'conv+gn cfg {cfg}')
     _check_gstat(res[0][0], res[0][1].view(B, H * W_, Cout), cg, coff, f'conv statistics cfg {cfg}')
+
+
+@pytest.mark.parametrize('B,H,W_,Cin,Cout,splitk,res,rowb,silu,eps', [(2, 8, 8, 1280, 1280, 5, 1, 0, 1, 1e-5), (8, 4, 4, 640, 1280, 0, 0, 1, 1, 1e-5),
+                                                                    (3, 16, 16, 320, 640, 3, 1, 1, 0, 1e-6), (2, 32, 32, 128, 320, 2, 0, 1, 1, 1e-5),
+                                                                    (5, 4, 12, 256, 256, 4, 1, 1, 1, 1e-5)])
+def test_splitk_conv_feeds_groupnorm_from_its_slabs(B, H, W_, Cin, Cout, splitk, res, rowb, silu, eps):
+    """mkd_gemm_groupnorm_bf16: [split-K conv3x3 -> fp32 slabs][ONE kernel: reduce + epilogue + GroupNorm(+SiLU)] vs torch, and
+    BIT-IDENTICAL to the three-kernel path (conv + split-K reduce, then mkd_groupnorm) on both outputs."""
+    lib = L()
+    hw, M, K = H * W_, B * H * W_, 9 * Cin
+    g = torch.Generator().manual_seed(B * hw + Cin + Cout)
+    x = torch.randn(B, Cin, H, W_, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    rowbias = torch.randn(B, Cout, generator=g).to(DEV) if rowb else None
+    R = bf(torch.randn(M, Cout, generator=g)) if res else None
+    gamma = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV); beta = (0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    xb = bf(x); wbf = bf(w)
+    xn = xb.permute(0, 2, 3, 1).contiguous()
+    wp = torch.empty(Cout, K, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(wbf.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    raw = torch.zeros(M, Cout, device=DEV, dtype=torch.bfloat16); y = torch.zeros(M, Cout, device=DEV, dtype=torch.bfloat16)
+    rc = lib.mkd_gemm_groupnorm_bf16(P(xn), Cin, P(wp), K, P(bias), P(rowbias), Cout if rowb else 0, hw, P(R), Cout if res else 0, 1.0, P(raw), Cout, 1,
+                                     M, Cout, K, 1, B, H, W_, Cin, H, W_, 1, 0, splitk, hw, P(gamma), P(beta), eps, silu, P(y), Cout, None)
+    if rc == -4:
+        pytest.skip(lib.mkd_last_error().decode())
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    conv = F.conv2d(xb.float(), wbf.float(), bias, padding=1)
+    if rowb:
+        conv = conv + rowbias[:, :, None, None]
+    if res:
+        conv = conv + R.float().view(B, H, W_, Cout).permute(0, 3, 1, 2)
+    assert_close_bf16(raw.float().view(B, H, W_, Cout).permute(0, 3, 1, 2), conv, what='raw conv output')
+    ref = F.group_norm(raw.float().view(B, hw, Cout).permute(0, 2, 1), 32, gamma, beta, eps)      # statistics of the STORED bf16 tensor
+    if silu:
+        ref = F.silu(ref)
+    assert_close_bf16(y.float().view(B, hw, Cout).permute(0, 2, 1), ref, what='GroupNorm from slabs')
+    # the separate kernels
+    raw2 = gemm(xn, wp, bias=bias, rowbias=rowbias, rpb=hw, R=R, conv=(B, H, W_, Cin, H, W_, 1, 0), lda=Cin, splitk=splitk)
+    y2 = torch.zeros_like(y)
+    assert lib.mkd_groupnorm(P(raw2), Cout, P(gamma), P(beta), eps, silu, P(y2), Cout, B, hw, Cout, 32, None) == 0
+    sync()
+    assert torch.equal(raw, raw2), 'raw output differs from the split-K reduce kernel'
+    assert torch.equal(y, y2), 'GroupNorm output differs from the two-kernel path'
+    # without the raw output the normalised one must not change
+    y3 = torch.zeros_like(y)
+    junk = torch.full_like(raw, 7.0)
+    rc = lib.mkd_gemm_groupnorm_bf16(P(xn), Cin, P(wp), K, P(bias), P(rowbias), Cout if rowb else 0, hw, P(R), Cout if res else 0, 1.0, P(junk), Cout, 0,
+                                     M, Cout, K, 1, B, H, W_, Cin, H, W_, 1, 0, splitk, hw, P(gamma), P(beta), eps, silu, P(y3), Cout, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    assert torch.equal(y3, y) and (junk == 7.0).all()
