@@ -168,7 +168,8 @@ struct mkd_ctx {
     float* gn_ws[NA] = {}; size_t gn_ws_bytes[NA] = {}, gn_need = 0;
     hipStream_t side_streams[NS] = {};        // [0] unused (the caller's stream)
     hipStream_t stream_of(int sid) const { return (arena_of(sid) == 0 || run_serial) ? run_main : side_streams[arena_of(sid)]; }
-    hipStream_t run_main = nullptr; bool run_serial = false; bool dual_stream = true;
+    hipStream_t run_main = nullptr; bool run_serial = false;
+    bool dual_stream = getenv("MKD_DUAL_STREAM") ? atoi(getenv("MKD_DUAL_STREAM")) != 0 : true;      // 0: the whole plan on the caller's stream (experiments)
     // measured at batch 8, 256x256 (ms per evaluation): no lanes 6.78, 2 decoder lanes 6.58, 4 decoder lanes 6.89, encoder lanes
     // on top +0.25: the encoder phase already runs two nets side by side, a third and fourth stream only add contention
     int dec_lanes = getenv("MKD_DEC_LANES") ? atoi(getenv("MKD_DEC_LANES")) : 2;          // 0 / 2 / 4 half- or quarter-batch decoder lanes

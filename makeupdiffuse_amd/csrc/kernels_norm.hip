@@ -307,7 +307,7 @@ struct SlabGn {
 };
 
 template <int NV>
-__global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_slab_kernel(const SlabGn a, bf16_t* __restrict__ y, int ld_out,
+__global__ __launch_bounds__(512) void gn_slab_kernel(const SlabGn a, bf16_t* __restrict__ y, int ld_out,
                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                        float eps, int silu, int hw, int C, int groups, int gpb) {
     extern __shared__ __attribute__((aligned(16))) float s_red[];
@@ -723,8 +723,7 @@ static bool gn_slab_shape(int hw, int C, int* gpb_out, int* nt_out, int* per_out
     int nt, per;
     if (per_of(256) <= 16) { nt = 256; per = per_of(256); }
     else if (per_of(512) <= 16) { nt = 512; per = per_of(512); }
-    else if (per_of(1024) <= 8) { nt = 1024; per = per_of(1024); }
-    else return false;
+    else return false;                     // (1024 threads would leave 128 registers for 16 slab loads in flight: spills)
     *gpb_out = gpb; *nt_out = nt; *per_out = per;
     return true;
 }
