@@ -181,8 +181,10 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
                   int stride, int up, int splitk, void* stream);
 /* LayerNorm fused into a linear GEMM: C = act(LN(A) . W^T + b) computed as rstd*(A.W'^T - mu*s) + b' on the RAW rows of A.
  * mkd_fold_layernorm builds W' = bf16(W*gamma) (written to rows dst_row0 + n*dst_row_mul of w_out), s = rowsum(W'),
- * b' = bias + W.beta from fp32 W [N,K] (device).  mkd_gemm_ln_bf16 runs the fused GEMM (no split-K); the row sums
- * come from the GEMM that produced A: row_stats [stat_slots][M][2] = partial (sum, sum of squares) per column slot.
+ * b' = bias + W.beta from fp32 W [N,K] (device).  mkd_gemm_ln_bf16 runs the fused GEMM (no split-K).  row_stats == NULL (the
+ * form the engine uses): the GEMM takes the row statistics itself from the A fragments it holds (ones . A^T and the diagonal of
+ * A . A^T on the matrix cores) - any A, no producer involved.  Otherwise the row sums come from the GEMM that produced A:
+ * row_stats [stat_slots][M][2] = partial (sum, sum of squares) per column slot.
  * mkd_gemm_rowstats_bf16 is that producer: C = A.W^T + bias + R (bf16) and the partial row sums of the rounded C. */
 int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
                        uint16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, void* stream);

@@ -119,6 +119,13 @@ struct mkd_ctx {
     // but measured neutral-to-slower in the pipeline (the consumer inherits the producer's write-back wait that the
     // LayerNorm kernel used to absorb), so it is opt-in: MKD_FUSE_LN=1.
     bool fuse_ln = false;
+    // LayerNorm "on the fly" (MKD_LN_FLY): the consumer GEMM (attn1 q|k|v, attn2 to_q, the GEGLU projection) runs on the raw rows with
+    // the gamma-folded weights and takes the row statistics itself from its A fragments (two extra MFMAs per row fragment and
+    // k-step); no LayerNorm kernel, nothing asked of the producer.  Removes 96 launches per evaluation.
+    // Bit mask: 1 = norm1 (-> q|k|v), 2 = norm2 (-> attn2.to_q), 4 = norm3 (-> GEGLU projection).  Measured at batch 8, 256x256
+    // (images/s): 0: 26.13, 2: 26.53, 3: 26.41, 7: 25.78 - every column tile of a wide consumer (N = 3d, 8d) repeats the statistics
+    // MFMAs (+26 % on the M = 8192, N = 2560 GEGLU projection), the d x d to_q GEMM pays 2-7 % for a 5 us LayerNorm launch -> 2.
+    int ln_fly = getenv("MKD_LN_FLY") ? atoi(getenv("MKD_LN_FLY")) : 2;
     // MKD_GN_FUSED=1: GroupNorm statistics emitted by the producing kernel's epilogue (deterministic fixed-point atomics) + an
     // element-wise apply kernel, instead of the two-phase GroupNorm kernel.  Built, parity-tested - and OFF by default: measured at
     // batch 8, 256x256 the producers' device-scope atomics cost 0.36 ms per evaluation (6.43 vs 6.18 ms; with the atomics stubbed
@@ -746,12 +753,15 @@ struct mkd_ctx {
         // Two variants.  fuse_ln: LayerNorm1/2/3 never run as kernels - the GEMM that PRODUCES h0/h1/h2 emits per-column-
         // tile partial row sums of its rounded output and the GEMM that CONSUMES LN(h) applies rstd*(acc - mu*rowsum(W'))
         // in its epilogue.  Default: LayerNorm kernels feeding the same folded... no: the plain weights.
+        // Third variant (ln_fly, the default): the consumer takes the row statistics itself (gemm_kernel LN < 0); producers untouched.
         const int slots = gemm_stat_slots(M, d, d);
-        const bool fl = fuse_ln && slots <= 20;
+        const bool fo = fuse_ln && slots <= 20;                  // producer-statistics form, all three norms
+        const bool fy1 = !fuse_ln && (ln_fly & 1), fy2 = !fuse_ln && (ln_fly & 2), fy3 = !fuse_ln && (ln_fly & 4);
+        const bool fl = fo;
         auto sbuf = [&]() { return fl ? (float*)TA().alloc((size_t)slots * M * 2 * sizeof(float)) : nullptr; };
         float* st0 = sbuf(); float* st1 = sbuf(); float* st2 = sbuf();
-        auto ln_input = [&](const bf16_t* hsrc, const std::string& norm, int ldh = 0) -> const bf16_t* {      // plain path: LN kernel
-            if (fl) return hsrc;
+        auto ln_input = [&](const bf16_t* hsrc, const std::string& norm, int ldh = 0, bool fused = false) -> const bf16_t* {      // plain path: LN kernel
+            if (fused) return hsrc;
             bf16_t* y = buf(d);
             op_ln(hsrc, wf(t + norm + ".weight"), wf(t + norm + ".bias"), y, M, d, ldh);
             return y;
@@ -762,9 +772,9 @@ struct mkd_ctx {
         { Epi e; e.bias = wf(p + ".proj_in.bias"); e.stat_out = st0; op_linear(g, d, M, d, wb(p + ".proj_in.weight"), d, e, h0, d); }
         // self attention
         bf16_t* qkv = buf(3 * d);
-        { Epi e; const bf16_t* a_in = ln_input(h0, ".norm1");
-          if (fl) { e.bias = qkv_b.at(p); e.ln_s = qkv_s.at(p); e.stat_in = st0; e.stat_slots = slots; }
-          op_linear(a_in, d, M, d, fl ? qkv_w.at(p) : qkv_plain.at(p), 3 * d, e, qkv, 3 * d); }
+        { Epi e; const bool f = fl || fy1; const bf16_t* a_in = ln_input(h0, ".norm1", 0, f);
+          if (f) { e.bias = qkv_b.at(p); e.ln_s = qkv_s.at(p); e.stat_in = fl ? st0 : nullptr; e.stat_slots = fl ? slots : 0; }
+          op_linear(a_in, d, M, d, f ? qkv_w.at(p) : qkv_plain.at(p), 3 * d, e, qkv, 3 * d); }
         bf16_t* a1 = buf(d);
         op_attn(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, a1, d, x.B, T, T, heads, dh);
         bf16_t* h1 = buf(d);
@@ -772,9 +782,9 @@ struct mkd_ctx {
           op_linear(a1, d, M, d, wb(t + ".attn1.to_out.0.weight"), d, e, h1, d); }
         // cross attention (K/V cached at prepare)
         bf16_t* q2 = buf(d);
-        { Epi e; const bf16_t* a_in = ln_input(h1, ".norm2");
-          if (fl) { e.bias = q2_b.at(p); e.ln_s = q2_s.at(p); e.stat_in = st1; e.stat_slots = slots; }
-          op_linear(a_in, d, M, d, fl ? q2_w.at(p) : wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
+        { Epi e; const bool f = fl || fy2; const bf16_t* a_in = ln_input(h1, ".norm2", 0, f);
+          if (f) { e.bias = q2_b.at(p); e.ln_s = q2_s.at(p); e.stat_in = fl ? st1 : nullptr; e.stat_slots = fl ? slots : 0; }
+          op_linear(a_in, d, M, d, f ? q2_w.at(p) : wb(t + ".attn2.to_q.weight"), d, e, q2, d); }
         Tensor kv = kv_cache.at(p);
         kv.p += (size_t)b0 * ctx_len() * kv.ld;
         bf16_t* a2 = buf(d);
@@ -786,10 +796,10 @@ struct mkd_ctx {
         // GEGLU feed-forward: Linear(d, 8d) + GEGLU in one GEMM (epilogue writes a * gelu(gate), 4d columns)
         bf16_t* gg = mf ? cat5 : buf(4 * d);
         const int ldg = mf ? 5 * d : 4 * d;
-        { Epi e; const bf16_t* a_in = ln_input(h2, ".norm3", ldh2); e.act = 2;
-          if (fl) { e.bias = ffg_b.at(p); e.ln_s = ffg_s.at(p); e.stat_in = st2; e.stat_slots = slots; }
+        { Epi e; const bool f = fl || fy3; const bf16_t* a_in = ln_input(h2, ".norm3", ldh2, f); e.act = 2;
+          if (f) { e.bias = ffg_b.at(p); e.ln_s = ffg_s.at(p); e.stat_in = fl ? st2 : nullptr; e.stat_slots = fl ? slots : 0; }
           else e.bias = ffp_b.at(p);
-          op_linear(a_in, d, M, d, fl ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, ldg); }
+          op_linear(a_in, f ? ldh2 : d, M, d, f ? ffg_w.at(p) : ffp_w.at(p), 8 * d, e, gg, ldg); }
         if (mf) {
             Epi e; e.bias = ffm_b.at(p); e.R = x.p; e.ldr = x.ld; e.gn = go;
             op_linear(cat5, 5 * d, M, 5 * d, ffm_w.at(p), d, e, out, ldo);
@@ -2031,7 +2041,7 @@ int mkd_fold_layernorm(const float* w, const float* gamma, const float* beta, co
 }
 int mkd_gemm_ln_bf16(const uint16_t* A, int lda, const uint16_t* Wfold, int ldw, const float* bias_fold, const float* ln_s,
                      const float* row_stats, int stat_slots, float eps, int act, void* C, int ldc, int M, int N, int K, void* stream) {
-    if (!A || !Wfold || !C || !ln_s || !row_stats) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_ln_bf16: null pointer");
+    if (!A || !Wfold || !C || !ln_s) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_ln_bf16: null pointer");          // row_stats null: on the fly
     if (!g_zero) {
         MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
         MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));

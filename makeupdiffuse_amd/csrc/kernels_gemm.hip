@@ -47,9 +47,15 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
     constexpr int NI = TN / WN / 16;      // W fragments (16 rows) per wave
     constexpr int MI = TM / WM / 16;      // X fragments (16 rows) per wave
     static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8), "tile/wave layout");
-    static_assert(STAGES >= 2 && STAGES <= 6 && 4 * (XP + WP) + (LN ? MI * (LN > 0 ? LN : 1) : 0) < 64, "vmcnt immediates");
+    static_assert(STAGES >= 2 && STAGES <= 6 && 4 * (XP + WP) + (LN > 0 ? MI * LN : 0) < 64, "vmcnt immediates");
     static_assert(!(LN && GNS), "fused LayerNorm and GroupNorm statistics are separate kernels");
-    static_assert(KW == 1 || (!LN && !GNS), "in-block K split: plain epilogue only");
+    // LN < 0: LayerNorm of the A rows "on the fly": the GEMM runs on the RAW rows with gamma-folded weights (as LN > 0) and takes
+    // the row statistics itself, from the A fragments it already holds, with two extra MFMAs per row fragment and k-step -
+    // ones . X^T gives the row sums, the diagonal of X . X^T the sums of squares - so no LayerNorm kernel and no producer-side
+    // statistics are needed.  These layers are latency-bound (MFMA pipe < 15 % busy): the extra MFMAs are hidden.
+    constexpr bool LNF = LN < 0;
+    static_assert(KW == 1 || (LN <= 0 && !GNS), "in-block K split: plain epilogue (or on-the-fly LayerNorm) only");
+    static_assert(!LNF || !CONV, "LayerNorm fusion is for linear GEMMs");
     static_assert(KW >= 1 && KW <= 4 && (KW - 1) * TM * TN * 4 <= KW * STAGES * STAGE, "in-block K split: partial tiles are summed in the rings");
     constexpr int LPT = XP + WP;          // global_load_lds per wave per K-tile (exact)
 
@@ -151,6 +157,12 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
+    f32x4 ssum[LNF ? MI : 1], ssq[LNF ? MI : 1];          // LNF: row sums (every register) / X . X^T (diagonal = sums of squares)
+#pragma unroll
+    for (int mi = 0; mi < (LNF ? MI : 1); ++mi) { ssum[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     auto compute = [&](int buf) {
         const char* xs = smg + buf * STAGE;
@@ -174,13 +186,20 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            if (LNF) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    ssum[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[mi], ssum[mi], 0, 0, 0);
+                    ssq[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mi], xf[mi], ssq[mi], 0, 0, 0);
+                }
+            }
         }
     };
 
     const float* const stat_in = p.stat_in; const int stat_in_slots = p.stat_in_slots;
     float* const stat_out = p.stat_out;
     constexpr int SL = LN > 0 ? LN : 1;          // LN = 0: off; 1 / 3 / 5: stat loads per lane per row
-    float2 lnt[LN ? MI : 1][SL];
+    float2 lnt[LN > 0 ? MI : 1][SL];
 
     // ---- K loop: STAGES-deep LDS ring, STAGES-1 tiles of global_load_lds in flight across each barrier ----
     // Every wave issues exactly LPT loads per tile, in order, so "tile i landed" == "at most LPT * (tiles
@@ -230,8 +249,8 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         // retire in order, so issued earlier they would hold up the first tile wait of every block (their lines
         // were just written by the producer GEMM, possibly through another XCD's L2).  Being younger than tiles
         // 0..STAGES-2 they add a constant NST to the counted waits of the first STAGES-1 iterations only.
-        constexpr int NST = LN ? MI * SL : 0;
-        if (LN) {
+        constexpr int NST = LN > 0 ? MI * SL : 0;
+        if (LN > 0) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 ln_stats_issue<SL>(stat_in, stat_in_slots, M, m0 + wm * (TM / WM) + mi * 16 + frow, fq, lnt[mi]);
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         int nxt = STAGES - 1;                      // ring slot the next prefetch goes to
         for (int i = 0; i < ntile; ++i) {
             const int after = min(STAGES - 2, ntile - 1 - i);      // tiles issued after tile i
-            const int nst = (LN && i < STAGES - 1) ? NST : 0;
+            const int nst = (LN > 0 && i < STAGES - 1) ? NST : 0;
             // counted wait: N = LPT * after (+ NST); immediates only, hence the switch
             if (nst) {
                 switch (after) {
@@ -273,20 +292,37 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         __syncthreads();
         f32x4* const red = (f32x4*)smem;
         const int slot = w * 64 + lane;
+        constexpr int NF = NI * MI + (LNF ? 2 * MI : 0);          // fragments per thread (+ the LayerNorm statistics tiles)
+        static_assert((KW - 1) * NF * NW * 64 * 16 <= KW * STAGES * STAGE, "partial tiles must fit in the rings");
         if (kg > 0) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) red[((kg - 1) * (NI * MI) + ni * MI + mi) * (NW * 64) + slot] = acc[ni][mi];
+                for (int mi = 0; mi < MI; ++mi) red[((kg - 1) * NF + ni * MI + mi) * (NW * 64) + slot] = acc[ni][mi];
+            if (LNF) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    red[((kg - 1) * NF + NI * MI + mi) * (NW * 64) + slot] = ssum[mi];
+                    red[((kg - 1) * NF + NI * MI + MI + mi) * (NW * 64) + slot] = ssq[mi];
+                }
+            }
         }
         __syncthreads();
         if (kg > 0) return;
 #pragma unroll
-        for (int g = 1; g < KW; ++g)            // fixed order: deterministic
+        for (int g = 1; g < KW; ++g) {          // fixed order: deterministic
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] += red[((g - 1) * (NI * MI) + ni * MI + mi) * (NW * 64) + slot];
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] += red[((g - 1) * NF + ni * MI + mi) * (NW * 64) + slot];
+            if (LNF) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    ssum[mi] += red[((g - 1) * NF + NI * MI + mi) * (NW * 64) + slot];
+                    ssq[mi] += red[((g - 1) * NF + NI * MI + MI + mi) * (NW * 64) + slot];
+                }
+            }
+        }
     }
     if constexpr (GNS != 0) {
         // ---- epilogue with GroupNorm statistics (split-K launches use the plain kernel + splitk_epilogue_gn_kernel) ----
@@ -340,7 +376,18 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         const int m = m0 + wm * (TM / WM) + mi * 16 + frow;
         const bool mok = m < M;
         float mu = 0.f, rstd = 1.f;
-        if (LN) ln_stats_finish<SL>(lnt[mi], stat_in_slots, fq, K, ln_eps, mu, rstd);
+        if (LN > 0) ln_stats_finish<SL>(lnt[mi], stat_in_slots, fq, K, ln_eps, mu, rstd);
+        if (LNF) {
+            // this lane's column m = frow: its row sum sits in every register of ssum; its sum of squares is the diagonal element of
+            // X . X^T, held by the lane of the same column whose row block is fq' = frow >> 2, in register frow & 3
+            const int r = frow & 3;
+            const float d = r == 0 ? ssq[mi][0] : (r == 1 ? ssq[mi][1] : (r == 2 ? ssq[mi][2] : ssq[mi][3]));
+            const float q = __shfl(d, frow + 16 * (frow >> 2), 64);
+            const float mean = ssum[mi][0] / (float)K;
+            float var = q / (float)K - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            mu = mean; rstd = rsqrtf(var + ln_eps);
+        }
         float ps = 0.f, pq = 0.f;          // partial row sum / sum of squares of this lane's output columns
         if (mok) {
 #pragma unroll
@@ -630,7 +677,7 @@ static int gemm_resolve_plan(const GemmArgs& a, GemmPlan* out) {
         g.per = (a.K + BK - 1) / BK;
     }
     if (a.stat_out) g = stat_producer_plan(g);
-    if (kTileKW[g.cfg] > 1 && (a.ln_s || a.stat_out || (a.gn_stat && g.splitk == 1))) g.cfg = kTileBase[g.cfg];     // plain epilogue only
+    if (kTileKW[g.cfg] > 1 && ((a.ln_s && a.stat_in) || a.stat_out || (a.gn_stat && g.splitk == 1))) g.cfg = kTileBase[g.cfg];     // plain epilogue (or on-the-fly LayerNorm) only
     if (is_patch_cfg(g.cfg) && !conv_patch_supported(a, g.cfg)) {
         if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
         g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0, /*pin_cfg=*/1);
@@ -676,6 +723,16 @@ static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
     }
     dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
     dim3 block(64 * WM * WN * KW);
+    if (a.ln_s) {          // on-the-fly LayerNorm (resolve keeps in-block K split only for that form)
+        static bool lattr = false;
+        if (lds > 64 * 1024 && !lattr) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1, 0, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+            lattr = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1, 0, KW>), grid, block, lds, stream, a);
+        return 0;
+    }
     if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
     else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
     return 0;
@@ -706,6 +763,16 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
         else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 1>), grid, block, lds, stream, a);
         return 0;
     }
+    if (a.ln_s && !a.stat_in) {          // LayerNorm statistics taken by the GEMM itself
+        static bool lf_attr = false;
+        if (lds > 64 * 1024 && !lf_attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+            lf_attr = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1>), grid, block, lds, stream, a);
+        return 0;
+    }
     if (a.ln_s) {
         static bool ln_attr = false;
         if (lds > 64 * 1024 && !ln_attr) {
@@ -734,8 +801,8 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
     if (a.R && (a.ldr % 4)) return mkd_fail(-1, "gemm: ldr must be a multiple of 4");
     if (a.rowbias && a.rows_per_batch <= 0) return mkd_fail(-1, "gemm: rows_per_batch");
     if (a.ln_s && (a.conv || a.K > 8192)) return mkd_fail(-1, "gemm: fused LayerNorm is for linear GEMMs");
-    if (a.ln_s && (!a.stat_in || a.stat_in_slots <= 0 || a.stat_in_slots > 20))
-        return mkd_fail(-1, "gemm: fused LayerNorm needs the producer's row statistics in 1..20 column slots");
+    if (a.ln_s && a.stat_in && (a.stat_in_slots <= 0 || a.stat_in_slots > 20))
+        return mkd_fail(-1, "gemm: fused LayerNorm with producer statistics needs them in 1..20 column slots");
     if (a.stat_out && (a.conv || a.act == 2 || a.out_f32)) return mkd_fail(-1, "gemm: row statistics are emitted by plain bf16 linear GEMMs only");
     if (a.gn_stat && (a.act == 2 || a.out_f32 || a.stat_out || a.ln_s || a.gn_cg <= 0 || a.gn_hw <= 0 || a.gn_coff < 0 || (a.gn_coff + a.N + a.gn_cg - 1) / a.gn_cg > 32))
         return mkd_fail(-1, "gemm: GroupNorm statistics need a plain bf16 output, rows per sample, channels per group, <= 32 groups");

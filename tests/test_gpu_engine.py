@@ -282,3 +282,31 @@ def test_groupnorm_producer_statistics_plan_matches_golden(dec_lanes, monkeypatc
     check_eps(a, G['x5'], rel=1.5e-2, cos=0.9999, what='5-step latent, fused GroupNorm statistics')
     assert torch.equal(a, b)
     eng.close()
+
+
+@pytest.mark.parametrize('mask', [0, 2, 7])
+def test_layernorm_on_the_fly_plans_match_golden(mask, monkeypatch):
+    """MKD_LN_FLY bit mask (norm1 / norm2 / norm3 folded into the consuming GEMM, row statistics taken inside it): every choice
+    gives the golden eps (with the fixture's random LayerNorm gamma / beta), bit-repeatable after poisoning, graph == eager."""
+    monkeypatch.setenv('MKD_LN_FLY', str(mask))
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.load_state_dict(sd)
+    G = {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
+    eng.prepare(G['hint'], G['ctx'])
+    first = None
+    for i in range(3):
+        eng.debug_poison()
+        out = eng.eps(G['x'], G['t'])
+        check_eps(out, G['eps'], what=f'MKD_LN_FLY={mask} rep {i}')
+        first = out if first is None else first
+        assert torch.equal(out, first)
+    sch = sampler.Schedule().make_ddim(5)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    a = eng.sample(G['x'], *args, use_graph=False)
+    b = eng.sample(G['x'], *args, use_graph=True)
+    check_eps(a, G['x5'], rel=1.5e-2, cos=0.9999, what=f'5-step latent, MKD_LN_FLY={mask}')
+    assert torch.equal(a, b)
+    eng.close()

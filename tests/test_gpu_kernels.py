@@ -574,3 +574,40 @@ def test_splitk_conv_feeds_groupnorm_from_its_slabs(B, H, W_, Cin, Cout, splitk,
     assert rc == 0, lib.mkd_last_error()
     sync()
     assert torch.equal(y3, y) and (junk == 7.0).all()
+
+
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 3, 4, 5, 14, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29])
+@pytest.mark.parametrize('M,d,N2,act', [(300, 320, 960, 0), (128, 1280, 1280, 0), (1024, 640, 5120, 2), (77, 64, 128, 0)])
+def test_gemm_layernorm_on_the_fly(cfg, M, d, N2, act):
+    """C = act(LN(A) . W^T + b) with the row statistics taken INSIDE the GEMM (row_stats = NULL: ones . A^T and diag(A . A^T) on the
+    matrix cores), every tile configuration incl. the in-block K split, GEGLU epilogue, a stride on A, rows with a large common
+    offset (the mean-subtraction path) - vs torch layer_norm -> linear."""
+    lib = L()
+    g = torch.Generator().manual_seed(M + d + N2 + 7 * cfg)
+    lda = d + 64
+    Ab = bf(torch.randn(M, lda, generator=g) + torch.randn(M, 1, generator=g) * 2.0)
+    Ab[:, d:] = 55.0                                   # beyond the row: must not enter the statistics
+    A = Ab[:, :d]
+    W2 = (torch.randn(N2, d, generator=g) / math.sqrt(d)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV); beta = (0.2 * torch.randn(d, generator=g)).to(DEV)
+    b2 = torch.randn(N2, generator=g).to(DEV)
+    Wf = torch.empty(N2, d, device=DEV, dtype=torch.bfloat16); s = torch.empty(N2, device=DEV); bfold = torch.empty(N2, device=DEV)
+    if act == 2:          # GEGLU: (value, gate) rows interleaved, as the engine folds ff.net.0.proj
+        inner = N2 // 2
+        for half in range(2):
+            assert lib.mkd_fold_layernorm(P(W2[half * inner:]), P(gamma), P(beta), P(b2[half * inner:]), inner, d, P(Wf), half, 2, P(s), P(bfold), None) == 0
+    else:
+        assert lib.mkd_fold_layernorm(P(W2), P(gamma), P(beta), P(b2), N2, d, P(Wf), 0, 1, P(s), P(bfold), None) == 0
+    ncol = N2 // 2 if act == 2 else N2
+    out = torch.zeros(M, ncol, device=DEV, dtype=torch.bfloat16)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        rc = lib.mkd_gemm_ln_bf16(P(Ab), lda, P(Wf), d, P(bfold), P(s), None, 0, 1e-5, act, P(out), ncol, M, N2, d, None)
+        assert rc == 0, lib.mkd_last_error()
+        sync()
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    ref = F.linear(F.layer_norm(A.float(), (d,), gamma, beta, 1e-5), W2, b2)
+    if act == 2:
+        ref = ref[:, :inner] * F.gelu(ref[:, inner:])
+    assert_close_bf16(out, ref, rel=8e-3, what=f'on-the-fly layernorm gemm cfg {cfg}')
