@@ -186,9 +186,10 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-            if (LNF) {
+            if (LNF) {          // the WN waves that share these rows split the row fragments between them (shared through LDS at the end)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
+                    if (MI >= WN && (mi % WN) != wn) continue;          // (wave-uniform)
                     ssum[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[mi], ssum[mi], 0, 0, 0);
                     ssq[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mi], xf[mi], ssq[mi], 0, 0, 0);
                 }
@@ -324,6 +325,25 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
             }
         }
     }
+    // LNF: per-row (sum, sum of squares) of the whole tile in LDS: each wave publishes the row fragments it owns, all read theirs.
+    // KW == 1: the region behind the ring (other waves may still be reading the last tile); KW > 1: every wave is past its K loop.
+    float* const lnrow = (float*)(KW > 1 ? smem + KW * STAGES * STAGE - TM * 8 : smem + STAGES * STAGE);
+    if constexpr (LNF) {
+        static_assert(KW == 1 || (KW - 1) * (NI * MI + 2 * MI) * NW * 64 * 16 + TM * 8 <= KW * STAGES * STAGE, "LayerNorm row statistics behind the partial tiles");
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (MI >= WN && (mi % WN) != wn) continue;
+            // this lane's column m = frow: its row sum sits in every register of ssum; its sum of squares is the diagonal element of
+            // X . X^T, held by the lane of the same column whose row block is fq' = frow >> 2, in register frow & 3
+            const int r = frow & 3;
+            const float d = r == 0 ? ssq[mi][0] : (r == 1 ? ssq[mi][1] : (r == 2 ? ssq[mi][2] : ssq[mi][3]));
+            if (fq == (frow >> 2)) {
+                const int lr = wm * (TM / WM) + mi * 16 + frow;
+                lnrow[lr * 2] = ssum[mi][0]; lnrow[lr * 2 + 1] = d;
+            }
+        }
+        __syncthreads();
+    }
     if constexpr (GNS != 0) {
         // ---- epilogue with GroupNorm statistics (split-K launches use the plain kernel + splitk_epilogue_gn_kernel) ----
         // Fast path: column-fragment major; per fragment the lane's 4 channels are summed over the wave's row fragments in
@@ -378,12 +398,9 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         float mu = 0.f, rstd = 1.f;
         if (LN > 0) ln_stats_finish<SL>(lnt[mi], stat_in_slots, fq, K, ln_eps, mu, rstd);
         if (LNF) {
-            // this lane's column m = frow: its row sum sits in every register of ssum; its sum of squares is the diagonal element of
-            // X . X^T, held by the lane of the same column whose row block is fq' = frow >> 2, in register frow & 3
-            const int r = frow & 3;
-            const float d = r == 0 ? ssq[mi][0] : (r == 1 ? ssq[mi][1] : (r == 2 ? ssq[mi][2] : ssq[mi][3]));
-            const float q = __shfl(d, frow + 16 * (frow >> 2), 64);
-            const float mean = ssum[mi][0] / (float)K;
+            const int lr = wm * (TM / WM) + mi * 16 + frow;
+            const float q = lnrow[lr * 2 + 1];
+            const float mean = lnrow[lr * 2] / (float)K;
             float var = q / (float)K - mean * mean;
             var = var < 0.f ? 0.f : var;
             mu = mean; rstd = rsqrtf(var + ln_eps);
