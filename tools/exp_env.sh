@@ -8,10 +8,9 @@ except Exception as e:
     print("$name failed", e)
 PY
 }
-EXTRA="--graph 0"
-run eager A=1
-run mask1 MKD_CU_MASK=1
-run mask2 MKD_CU_MASK=2
-run mask1_nolanes MKD_CU_MASK=1 MKD_DEC_LANES=0
-run mask1_helpers MKD_CU_MASK=1 MKD_LANE_HELPERS=1
-run eager2 A=1
+# usage (on the GPU box): edit the legs below; each leg = a name + environment assignments for one bench run
+run base A=1
+run ln_fly0 MKD_LN_FLY=0
+run ln_fly3 MKD_LN_FLY=3
+run ln_fly7 MKD_LN_FLY=7
+run base2 A=1
