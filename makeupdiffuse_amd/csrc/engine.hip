@@ -126,6 +126,13 @@ struct mkd_ctx {
     // (images/s): 0: 26.13, 2: 26.53, 3: 26.41, 7: 25.78 - every column tile of a wide consumer (N = 3d, 8d) repeats the statistics
     // MFMAs (+26 % on the M = 8192, N = 2560 GEGLU projection), the d x d to_q GEMM pays 2-7 % for a 5 us LayerNorm launch -> 2.
     int ln_fly = getenv("MKD_LN_FLY") ? atoi(getenv("MKD_LN_FLY")) : 2;
+    // Transformers of at most ln_fly_rows rows (lane batch x tokens) take the mask ln_fly_small instead: with few rows the repeated
+    // statistics cost nothing and only the removed launch counts.  The default threshold follows the evaluated batch (MKD_LN_FLY_ROWS
+    // overrides; tools/exp_lnrows.sh, images/s without / with): batch 1 -> every transformer (6.51 / 6.70), batch 2 -> 256 rows
+    // (11.75 / 11.90), otherwise 128 rows (batch 4: 18.75 / 18.84; batch 8 and 16 unchanged, 256 rows would cost them 1.2 %: those
+    // are the split-K weight-streaming layers of the half-batch lanes, and statistics over the whole row forbid splitting K).
+    int ln_fly_small = getenv("MKD_LN_FLY_SMALL") ? atoi(getenv("MKD_LN_FLY_SMALL")) : 7;
+    int ln_fly_rows = getenv("MKD_LN_FLY_ROWS") ? atoi(getenv("MKD_LN_FLY_ROWS")) : -1;
     // MKD_GN_FUSED=1: GroupNorm statistics emitted by the producing kernel's epilogue (deterministic fixed-point atomics) + an
     // element-wise apply kernel, instead of the two-phase GroupNorm kernel.  Built, parity-tested - and OFF by default: measured at
     // batch 8, 256x256 the producers' device-scope atomics cost 0.36 ms per evaluation (6.43 vs 6.18 ms; with the atomics stubbed
@@ -756,7 +763,9 @@ struct mkd_ctx {
         // Third variant (ln_fly, the default): the consumer takes the row statistics itself (gemm_kernel LN < 0); producers untouched.
         const int slots = gemm_stat_slots(M, d, d);
         const bool fo = fuse_ln && slots <= 20;                  // producer-statistics form, all three norms
-        const bool fy1 = !fuse_ln && (ln_fly & 1), fy2 = !fuse_ln && (ln_fly & 2), fy3 = !fuse_ln && (ln_fly & 4);
+        const int fly_rows = ln_fly_rows >= 0 ? ln_fly_rows : (B <= 1 ? 1 << 30 : (B == 2 ? 256 : 128));
+        const int fly = getenv("MKD_LN_FLY") ? ln_fly : (M <= fly_rows ? ln_fly_small : ln_fly);      // an explicit MKD_LN_FLY applies to every size
+        const bool fy1 = !fuse_ln && (fly & 1), fy2 = !fuse_ln && (fly & 2), fy3 = !fuse_ln && (fly & 4);
         const bool fl = fo;
         auto sbuf = [&]() { return fl ? (float*)TA().alloc((size_t)slots * M * 2 * sizeof(float)) : nullptr; };
         float* st0 = sbuf(); float* st1 = sbuf(); float* st2 = sbuf();
