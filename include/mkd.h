@@ -14,6 +14,10 @@
  *   - external layout is the reference's: NCHW fp32 latents/images, [B,77,C] fp32 context,
  *     int64 timesteps.  Internally activations are NHWC bf16, accumulation fp32.
  *   - no internal host threads; a context is not re-entrant (one stream at a time).
+ *   - host synchronisation points (everything else only enqueues): mkd_ctx_create / mkd_weights_finalize / mkd_vae_finalize / mkd_clip_finalize
+ *     and the first mkd_prepare of a new shape (plan building, hipDeviceSynchronize); mkd_sample(use_graph != 0), which waits on the host
+ *     for the context's PREVIOUS graph-replayed loop before it rewrites the pinned step table (hipStreamSynchronize of the
+ *     private loop stream) and then returns with the new loop enqueued; mkd_eps_profile (measures, so it waits); mkd_ctx_destroy.
  */
 #ifndef MKD_H
 #define MKD_H
@@ -108,7 +112,8 @@ int mkd_ddim_step(const float* x, const float* eps_c, const float* eps_u, float 
  * batch B (cfg_scale == 1) or 2B with the UNCONDITIONAL conditioning first (cddim.py:25-31).
  * Tables are host arrays of length n_steps indexed like ddim_alphas[index]; the loop runs
  * index = n_steps-1 .. 0 with timestep = timesteps[index].  x_T, x_out: [B,4,h,w] fp32.
- * use_graph != 0 captures one step into a hipGraph and replays it. */
+ * use_graph != 0 captures one step into a hipGraph and replays it; such a call first waits (host) until the previous
+ * graph-replayed loop of this context has finished, see "host synchronisation points" above. */
 int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps,
                const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
                float cfg_scale, float* x_out, int use_graph, void* stream);
