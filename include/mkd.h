@@ -201,6 +201,11 @@ int mkd_gemm_rowstats_bf16(const uint16_t* A, int lda, const uint16_t* W, int ld
                            void* stream);
 /* Tuner / tests only: force the GEMM tile configuration (index into the table in kernels_gemm.hip; -1 = heuristic). */
 int mkd_gemm_force_tile(int cfg);
+/* Tests / experiments: workgroup -> tile order of the GEMM and LDS-staged conv kernels with respect to the 8 XCDs (each has its own
+ * L2; workgroups are dealt to them round-robin in launch order).  0 (default): launch order; 1: every XCD gets one contiguous run
+ * of the tile sequence with M-tiles fastest (a weight tile lives in one L2); 2: the same with N-tiles fastest.  Results do not
+ * depend on it (bit-identical).  Applies to launches issued afterwards. */
+int mkd_gemm_set_xcd_mode(int mode);
 /* Tests only (race detector): overwrite every buffer one mkd_eps produces (activations, temporaries, workspaces) with NaN
  * patterns, so that a kernel running ahead of its producer cannot see the previous call's values.  Synchronous. */
 int mkd_debug_poison(mkd_ctx* ctx);

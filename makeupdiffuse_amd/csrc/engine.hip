@@ -1928,6 +1928,7 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
                        (hipStream_t)stream);
 }
 int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
+int mkd_gemm_set_xcd_mode(int mode) { gemm_set_xcd_mode(mode); return 0; }
 int mkd_debug_poison(mkd_ctx* ctx) { return ctx ? ctx->debug_poison() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
 int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk) {
     gemm_set_override(M, N, K, conv3x3, stride, up, cfg, splitk);

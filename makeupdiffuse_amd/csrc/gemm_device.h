@@ -4,6 +4,24 @@
 
 namespace mkdk {
 
+// XCD-aware tile order.  The dispatcher deals workgroups to the 8 XCDs round-robin in launch order (x fastest), so workgroup `lid`
+// runs on XCD lid % 8 as the (lid / 8)-th workgroup there.  Give every XCD one CONTIGUOUS run of the tile sequence instead: tiles that
+// share an operand tile then sit in the same L2 at the same time.  Uniform (scalar) arithmetic only.
+__device__ __forceinline__ void xcd_tile_order(int mode, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (mode == 0) return;
+    const int gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * (int)gridDim.z;
+    const int lid = bx + gx * by + plane * bz;
+    const int xcd = lid & 7, idx = lid >> 3, q = total >> 3, r = total & 7;
+    const int t = xcd * q + (xcd < r ? xcd : r) + idx;       // XCD k owns tiles [k*q + min(k, r), ...): q (+1 for k < r) of them
+    bz = t / plane;
+    const int rem = t - bz * plane;
+    if (mode == 1) { by = rem / gx; bx = rem - by * gx; }    // x fastest: consecutive tiles share the W tile
+    else { bx = rem / gy; by = rem - bx * gy; }              // y fastest: consecutive tiles share the A tile
+}
+
+
+
 constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;

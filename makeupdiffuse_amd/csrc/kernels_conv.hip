@@ -51,14 +51,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     const int wm = w / WN, wn = w % WN;
     const int PH = TH + 2, PW = TW + 2, PPIX = PH * PW, NP = IMGS * PPIX;
     const int tiles_x = Wd / TW, tiles_y = H / TH;
-    const int bid = blockIdx.x;
+    int bid, by, bz;
+    xcd_tile_order(p.xcd_mode, bid, by, bz);
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
     const int b0 = (bid / (tiles_x * tiles_y)) * IMGS;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int n0 = blockIdx.y * TN;
+    const int n0 = by * TN;
     const int nch_total = Cin / BK;
-    const int c_begin = blockIdx.z * per;
+    const int c_begin = bz * per;
     const int c_end = min(nch_total, c_begin + per);
 
     char* const patch0 = smem;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
             if (n >= N) continue;
-            if (splitk > 1) *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
+            if (splitk > 1) *(f32x4*)(ws + ((size_t)bz * M + m) * N + n) = acc[ni][mi];
             else epilogue_write(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
         }
     }

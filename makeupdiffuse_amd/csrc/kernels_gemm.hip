@@ -22,6 +22,7 @@
 #include "mkd_common.h"
 #include "gemm_device.h"
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <tuple>
 
@@ -75,10 +76,12 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
     const int w = KW > 1 ? (tid >> 6) % NW : tid >> 6;        // wave inside its group
     char* const smg = smem + kg * (STAGES * STAGE);           // this group's ring
     const int wm = w / WN, wn = w % WN;
-    const int m0 = blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+    int bx, by, bz;
+    xcd_tile_order(p.xcd_mode, bx, by, bz);
+    const int m0 = bx * TM;
+    const int n0 = by * TN;
     const int nk_total = (K + BK - 1) / BK;
-    const int kt_begin = blockIdx.z * per;
+    const int kt_begin = bz * per;
     const int kt_end = min(nk_total, kt_begin + per);
 
     // ---- per-lane staging geometry -----------------------------------------------------------
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
                 const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
                 if (n >= N) continue;
                 if (splitk > 1) {
-                    *(f32x4*)(ws + ((size_t)blockIdx.z * M + m) * N + n) = acc[ni][mi];
+                    *(f32x4*)(ws + ((size_t)bz * M + m) * N + n) = acc[ni][mi];
                 } else {
                     const f32x4 v0 = LN ? ln_correct(ln_s, n, acc[ni][mi], mu, rstd) : acc[ni][mi];
                     const f32x4 r = epilogue_write(epi, m, n, pre ? epilogue_value_pre(epi, m, n, v0, pbias[ni], pres[ni][mi]) : epilogue_value(epi, m, n, v0));
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int c = 0; c < WN; ++c) { a += statlds[(c * TM + lr) * 2]; q += statlds[(c * TM + lr) * 2 + 1]; }
-            *(float2*)(stat_out + ((size_t)blockIdx.y * M + m) * 2) = float2{a, q};
+            *(float2*)(stat_out + ((size_t)by * M + m) * 2) = float2{a, q};
         }
     }
 }
@@ -610,6 +613,12 @@ void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cf
 static int g_force_cfg = -1;     // tuner / tests only
 static int g_splitk_cap = 0;      // experiment knob (MKD_SPLITK_CAP): 0 = no cap
 void gemm_set_splitk_cap(int cap) { g_splitk_cap = cap; }
+// XCD-aware tile order of every launch that does not ask for one itself (MKD_XCD_MODE / mkd_gemm_set_xcd_mode; GemmArgs::xcd_mode).
+// Default 0 = launch order: measured over the whole loop both contiguous-run orders lose (batch 8: 27.61 / 27.28 / 27.51 images/s for
+// 0 / 1 / 2, batch 1: 6.78 / 6.63 / 6.63, 512x512: 9.22 / 9.07 / 9.05; tools/exp_xcd.sh) - with M-tiles fastest and a multiple of 8 of
+// them the launch order already keeps an A tile in one L2, and the weight tiles are small next to 8 x 4 MB of L2.
+static int g_xcd_mode = getenv("MKD_XCD_MODE") ? atoi(getenv("MKD_XCD_MODE")) : 0;
+void gemm_set_xcd_mode(int mode) { g_xcd_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
 void gemm_force_tile_cfg(int cfg) { g_force_cfg = (cfg >= 0 && cfg < N_TILE_CFG) ? cfg : -1; }
 
 // Tile + split-K choice.  Large problems take the big tiles (more FLOP per byte staged through L2 -> LDS,
@@ -808,6 +817,7 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
 }
 
 int launch_gemm(GemmArgs a, hipStream_t stream) {
+    if (!a.xcd_mode) a.xcd_mode = g_xcd_mode;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mkd_fail(-1, "gemm: empty problem");
     if (a.N % 4) return mkd_fail(-1, "gemm: N must be a multiple of 4");
     if (a.K % 8 || a.ldw % 8 || a.lda % 8) return mkd_fail(-1, "gemm: K, lda, ldw must be multiples of 8");

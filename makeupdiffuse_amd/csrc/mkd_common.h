@@ -86,6 +86,9 @@ struct GemmArgs {
     // gn_cg channels per group OF THE CONSUMER's tensor, gn_coff = column of this output inside it (concat halves), gn_hw rows per sample
     long long* gn_stat; int gn_cg; int gn_coff; int gn_hw;
     int defer_epilogue;                     // split-K launches: leave the fp32 partial slabs in ws; the caller's next kernel reduces them (launch_gn_from_slabs)
+    // workgroup -> tile order for the 8 XCDs (workgroups are dealt round-robin to them in launch order, each XCD has its own L2):
+    // 0 launch order; 1 an XCD owns runs of M-tiles of one N-tile (the weight tile lives in ONE L2); 2 runs of N-tiles of one M-tile
+    int xcd_mode;
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
 
@@ -104,6 +107,7 @@ int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
 int  gemm_resolve(const GemmArgs& a, int* cfg, int* splitk);       // the (tile, split-K) launch_gemm will use for exactly these arguments
 int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip
+void gemm_set_xcd_mode(int mode);         // tests / experiments: 0 launch order, 1 / 2 contiguous runs per XCD (GemmArgs::xcd_mode)
 void gemm_force_tile_cfg(int cfg);           // tuner/tests: force a tile config (-1 = heuristic)
 void gemm_set_splitk_cap(int cap);
 void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cfg, int splitk);   // in-eval tuner; M <= 0 clears all

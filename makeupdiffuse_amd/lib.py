@@ -80,6 +80,7 @@ SIGNATURES = {
     'mkd_gn_colstats': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mkd_gn_apply_stats': (_I, [_P, _I, _P, _P, _F, _I, _P, _I, _I, _I, _I, _P, _P]),
     'mkd_gemm_force_tile': (_I, [_I]),
+    'mkd_gemm_set_xcd_mode': (_I, [_I]),
     'mkd_debug_poison': (_I, [_P]),
     'mkd_gemm_set_override': (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'mkd_gemm_cfg_supported': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),

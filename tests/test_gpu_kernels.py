@@ -611,3 +611,35 @@ def test_gemm_layernorm_on_the_fly(cfg, M, d, N2, act):
     if act == 2:
         ref = ref[:, :inner] * F.gelu(ref[:, inner:])
     assert_close_bf16(out, ref, rel=8e-3, what=f'on-the-fly layernorm gemm cfg {cfg}')
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_xcd_tile_order_is_a_permutation_of_the_tiles(mode):
+    """mkd_gemm_set_xcd_mode: the workgroup -> tile remap (one contiguous run of the tile sequence per XCD) must visit every tile
+    exactly once whatever the grid (tile counts not divisible by 8, split-K planes, the LDS-staged conv's spatial tiles): results
+    bit-identical to the launch order."""
+    lib = L()
+    g = torch.Generator().manual_seed(77 + mode)
+    cases = []
+    for (M, N, K, splitk, cfg) in [(300, 320, 320, 1, 2), (1000, 640, 1344, 1, 3), (128, 1280, 2560, 4, 0), (96, 320, 200, 1, 1),
+                                   (8192, 320, 320, 1, 14), (520, 1280, 640, 3, 21), (77, 64, 64, 1, 0)]:
+        A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+        bias = torch.randn(N, generator=g).to(DEV)
+        cases.append((cfg, lambda A=A, W=W, bias=bias, splitk=splitk: gemm(A, W, bias=bias, splitk=splitk)))
+    for (B, H, Wd, Cin, Cout, splitk, cfg) in [(3, 16, 16, 64, 128, 1, 9), (8, 32, 32, 128, 192, 2, 9), (5, 8, 8, 128, 64, 1, 11)]:
+        x = bf(torch.randn(B, H, Wd, Cin, generator=g))
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+        assert lib.mkd_pack_conv_weight(P(bf(w).float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+        cases.append((cfg, lambda x=x, wp=wp, B=B, H=H, Wd=Wd, Cin=Cin, splitk=splitk: gemm(x, wp, conv=(B, H, Wd, Cin, H, Wd, 1, 0), splitk=splitk)))
+    for cfg, run in cases:
+        lib.mkd_gemm_force_tile(cfg)
+        try:
+            lib.mkd_gemm_set_xcd_mode(0)
+            ref = run()
+            lib.mkd_gemm_set_xcd_mode(mode)
+            out = run()
+        finally:
+            lib.mkd_gemm_set_xcd_mode(0)
+            lib.mkd_gemm_force_tile(-1)
+        assert torch.equal(out, ref), f'xcd mode {mode}, cfg {cfg}: differs from the launch order'
