@@ -94,6 +94,11 @@ def test_small_sample_loop(small):
     outg2 = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
                        use_graph=True)          # cached graph, counter re-armed
     assert torch.equal(outg, outg2)
+    # several steps per captured graph (MKD_GRAPH_STEPS, default 5) + single-step remainder (make_ddim(7) has 8 steps = 5 + 3, make_ddim(12) 13 = 5 + 5 + 3, 4 = remainder only)
+    for n in (7, 12, 4):
+        s_n = sampler.Schedule().make_ddim(n)
+        a_n = (s_n.ddim_timesteps, s_n.ddim_alphas, s_n.ddim_alphas_prev, s_n.ddim_sqrt_one_minus_alphas)
+        assert torch.equal(eng.sample(g['x'], *a_n, use_graph=True), eng.sample(g['x'], *a_n, use_graph=False)), f'{n} steps: graph != eager'
     # CFG 9: prepared with 2B, unconditional first (cddim.py:25-31), hint shared (diffusion_makeup.py:401)
     eng.prepare(torch.cat([g['hint'], g['hint']]), torch.cat([g['uctx'], g['ctx']]))
     out = eng.sample(g['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas,
