@@ -214,6 +214,7 @@ def test_full_size_eps_vs_oracle():
     ref = sampler.apply_model(sd, cfg, x, t, {'c_crossattn': [ctx], 'c_concat': [hint]})
     eng = MkdEngine(NetConfig())
     eng.load_state_dict(sd)
+    sd_ref = sd
     del sd
     eng.prepare(hint, ctx)
     r, c = check_eps(eng.eps(x, t), ref, what='full-size eps')
@@ -221,6 +222,15 @@ def test_full_size_eps_vs_oracle():
     # 121.42 GMAC per sample per eval, minus what mkd_prepare caches once per batch:
     # hint block 1.87 GMAC + cross-attention K/V projections 2.16 GMAC -> 117.39 GMAC executed per eval
     assert abs(eng.eps_flops() / 2e9 - 117.39) < 0.05
+    # BASELINE config 5 at full size: the blended hint embedding (alpha = 0.4 between two references) vs the oracle's restatement
+    hint2 = torch.cat([hint[:, :3], torch.rand(1, 3, 256, 256, generator=gen)], 1)
+    alpha = torch.tensor([0.4])
+    ref_i = sampler.apply_model(sd_ref, cfg, x, t, {'c_crossattn': [ctx], 'c_concat': [hint], 'c_concat2': [hint2], 'interp_alpha': alpha})
+    eng.prepare(hint, ctx, hint2=hint2, alpha=alpha)
+    out_i = eng.eps(x, t)
+    r, c = check_eps(out_i, ref_i, what='full-size interpolation eps')
+    print(f'full-size interpolation eps (alpha 0.4): rel-L2 {r:.4e} cos {c:.6f}')
+    assert (ref_i - ref).abs().max() > 1e-3          # the second reference does change the result
     eng.close()
 
 
