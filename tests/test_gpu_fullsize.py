@@ -162,3 +162,47 @@ def test_full_size_512_eps_vs_oracle():
     # K/V projections (2.16): 533.77 executed
     assert abs(eng.eps_flops() / 2e9 - 533.77) < 0.2, eng.eps_flops() / 2e9
     eng.close()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('steps', [20, 50])
+def test_full_size_cfg9_trajectory_and_image_vs_oracle(steps):
+    """The loop the reference runs, end to end at full size (B = 1, 256x256, eta 0, guidance scale 9 with the unconditional batch
+    first and the same hint: diffusion_makeup.py:308-309,391-410): 20 DDIM steps (BASELINE config 1) and the reference's default 50.
+    The whole trajectory of the 1.22 G-parameter nets and the decoded image vs the fp32 CPU oracle.  SURVEY.md §8c states the budget
+    for a bf16 trajectory: cosine >= 0.99, PSNR >= 30 dB.  2 x steps oracle evaluations (0.5-1.5 minutes of CPU)."""
+    import time
+    from oracle import nets, sampler, vae as ovae
+    from makeupdiffuse_amd.engine import VaeConfig
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    cfg = nets.FULL
+    sd = nets.init_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 32, 32, generator=gen); hint = torch.rand(1, 6, 256, 256, generator=gen)
+    ctx = torch.randn(1, 77, 768, generator=gen); uctx = torch.randn(1, 77, 768, generator=gen)
+    scale = 9.0
+    t0 = time.time()
+    ref = sampler.sample(sampler.make_eps_fn(sd, cfg), sampler.Schedule(), x, {'c_crossattn': [ctx], 'c_concat': [hint]}, steps,
+                         unconditional_guidance_scale=scale, unconditional_conditioning={'c_crossattn': [uctx], 'c_concat': [hint]})
+    t_oracle = time.time() - t0
+    vcfg = ovae.FULL
+    vsd = ovae.init_state_dict(vcfg, seed=0)
+    eng = MkdEngine(NetConfig())
+    eng.configure_vae(VaeConfig())
+    eng.load_state_dict({**sd, **vsd})
+    del sd
+    sch = DDIMSchedule().make_ddim(steps)
+    eng.prepare(torch.cat([hint, hint]), torch.cat([uctx, ctx]))
+    out = eng.sample(x, sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas, cfg_scale=scale,
+                     use_graph=True)
+    cos = torch.nn.functional.cosine_similarity(out.flatten().float().cpu(), ref.flatten(), dim=0).item()
+    r = rel(out, ref)
+    img_ref = ovae.decode_first_stage(vsd, vcfg, ref)
+    img = eng.decode(out).float().cpu()
+    peak = float(img_ref.max() - img_ref.min())
+    psnr = 10.0 * torch.log10(torch.tensor(peak * peak) / ((img - img_ref) ** 2).mean()).item()
+    cos_img = torch.nn.functional.cosine_similarity(img.flatten(), img_ref.flatten(), dim=0).item()
+    print(f'full-size {steps}-step CFG-9 trajectory: latent rel-L2 {r:.4e} cos {cos:.6f}; decoded image PSNR {psnr:.1f} dB (peak-to-peak {peak:.2f}) '
+          f'cos {cos_img:.6f}; oracle {t_oracle:.0f} s')
+    assert torch.isfinite(out).all() and cos >= 0.99 and psnr >= 30.0, (cos, psnr)
+    eng.close()
