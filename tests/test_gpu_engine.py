@@ -231,6 +231,20 @@ def test_full_size_eps_vs_oracle():
     r, c = check_eps(out_i, ref_i, what='full-size interpolation eps')
     print(f'full-size interpolation eps (alpha 0.4): rel-L2 {r:.4e} cos {c:.6f}')
     assert (ref_i - ref).abs().max() > 1e-3          # the second reference does change the result
+    # the remaining apply_model variants at full size (makeup_diffuse.py:164-170): decaying control_scales, only_mid_control, no hint
+    cond = {'c_crossattn': [ctx], 'c_concat': [hint]}
+    scales = [0.825 ** (12 - i) for i in range(13)]
+    for what, okw, ekw in (('control_scales', dict(control_scales=scales), dict(control_scales=scales)),
+                           ('only_mid_control', dict(only_mid_control=True), dict(only_mid_control=True))):
+        ref_v = sampler.apply_model(sd_ref, cfg, x, t, cond, **okw)
+        eng.prepare(hint, ctx, **ekw)
+        r, c = check_eps(eng.eps(x, t), ref_v, what=f'full-size eps, {what}')
+        print(f'full-size eps, {what}: rel-L2 {r:.4e} cos {c:.6f}')
+        assert (ref_v - ref).abs().max() > 1e-3
+    ref_n = sampler.apply_model(sd_ref, cfg, x, t, {'c_crossattn': [ctx], 'c_concat': None})
+    eng.prepare(None, ctx, latent_hw=(32, 32))
+    r, c = check_eps(eng.eps(x, t), ref_n, what='full-size eps, c_concat None')
+    print(f'full-size eps, c_concat None: rel-L2 {r:.4e} cos {c:.6f}')
     eng.close()
 
 
