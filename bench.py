@@ -112,28 +112,29 @@ def gen_weights(eng, seed, keep_cpu):
     return cpu
 
 
-def cpu_baseline(sd_cpu, res, x1, hint1, ctx1, gpu_eps1, n_evals, ddim_steps):
-    """The reference's CPU path cannot run here (ldm/cldm absent), so this times the fp32 torch RESTATEMENT
-    (oracle/, kind "port") on the host cores: BASELINE config 1 (B=1, fp32) bounded to n_evals eps evaluations."""
+def cpu_baseline(sd_cpu, res, x1, hint1, ctx1, gpu_eps1, gpu_lat, cpu_steps, ddim_steps):
+    """The reference's CPU path cannot run here (ldm/cldm absent), so this times the fp32 torch RESTATEMENT (oracle/, kind "port")
+    on the host cores: BASELINE config 1 END TO END - B=1, fp32, cpu_steps (20) DDIM steps from x_T, eta 0, no CFG - and scales
+    the time to the metric's ddim_steps.  One extra evaluation first checks the GPU's eps against the CPU's."""
     from oracle import nets, sampler
     threads = usable_cores()
     torch.set_num_threads(threads)
     cfg = nets.FULL
     cond = {'c_crossattn': [ctx1], 'c_concat': [hint1]}
-    t = torch.tensor([981])
-    times, ref = [], None
-    for i in range(n_evals):
-        t0 = time.perf_counter()
-        ref = sampler.apply_model(sd_cpu, cfg, x1, t, cond)
-        times.append(time.perf_counter() - t0)
-        log(f'cpu baseline eval {i + 1}/{n_evals}: {times[-1]:.2f} s on {threads} threads')
-    s_eval = float(np.median(times))
+    ref = sampler.apply_model(sd_cpu, cfg, x1, torch.tensor([981]), cond)
     rel = float(((gpu_eps1.cpu() - ref).norm() / ref.norm()).item())
     cos = float(torch.nn.functional.cosine_similarity(gpu_eps1.cpu().flatten(), ref.flatten(), dim=0).item())
+    t0 = time.perf_counter()
+    lat = sampler.sample(sampler.make_eps_fn(sd_cpu, cfg), sampler.Schedule(), x1, cond, cpu_steps)
+    s_run = time.perf_counter() - t0
+    log(f'cpu baseline: {cpu_steps}-step DDIM loop of B=1 in {s_run:.1f} s on {threads} threads')
+    s_eval = s_run / cpu_steps
+    lat_cos = float(torch.nn.functional.cosine_similarity(gpu_lat.cpu().flatten(), lat.flatten(), dim=0).item())
     return {'value': 1.0 / (s_eval * ddim_steps), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_evals} eps evaluations of B=1 {res}x{res} fp32 (oracle/ restatement, same weights); '
-                      f's/eval={s_eval:.3f}, x{ddim_steps} steps per image',
-            's_per_eval': s_eval, 'gpu_vs_cpu_eps_rel_l2': rel, 'gpu_vs_cpu_eps_cos': cos}
+            'sample': f'BASELINE config 1 end to end: B=1 {res}x{res} fp32, {cpu_steps} DDIM steps from x_T, eta 0, no CFG (oracle/ restatement, '
+                      f'same weights) in {s_run:.1f} s = {1.0 / s_run:.4f} images/s at {cpu_steps} steps; scaled x{ddim_steps}/{cpu_steps} to the metric',
+            's_per_eval': s_eval, 'config1_seconds': s_run, 'gpu_vs_cpu_eps_rel_l2': rel, 'gpu_vs_cpu_eps_cos': cos,
+            'gpu_vs_cpu_latent_cos_after_config1': lat_cos}
 
 
 def main():
@@ -148,7 +149,7 @@ def main():
     ap.add_argument('--interp', type=int, default=0, metavar='N_ALPHA',
                     help='BASELINE config 5: makeup interpolation sweep, --batch SOURCES per GPU x N_ALPHA alpha points (two references)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-evals', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=20, help='DDIM steps of the CPU baseline run (BASELINE config 1: 20; ~1.2 s each on 16 cores)')
     ap.add_argument('--graph', type=int, default=1, help='replay the DDIM step as a hipGraph (0 = eager launches)')
     ap.add_argument('--decode', type=int, default=1, help='1: VAE-decode the latents to images inside the timed step (images out)')
     ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
@@ -296,8 +297,11 @@ def main():
         if want_cpu:
             eng.prepare(hint[:1], ctx[:1])
             g1 = eng.eps(x_T[:1], torch.tensor([981], device=dev))
-            result['cpu_baseline'] = cpu_baseline(sd_cpu, args.res, x_T[:1].cpu(), hint[:1].cpu(), ctx[:1].cpu(), g1,
-                                                  args.cpu_evals, args.ddim_steps)
+            sch1 = DDIMSchedule().make_ddim(args.cpu_steps)
+            l1 = eng.sample(x_T[:1], sch1.ddim_timesteps, sch1.ddim_alphas, sch1.ddim_alphas_prev, sch1.ddim_sqrt_one_minus_alphas,
+                            use_graph=bool(args.graph))
+            result['cpu_baseline'] = cpu_baseline(sd_cpu, args.res, x_T[:1].cpu(), hint[:1].cpu(), ctx[:1].cpu(), g1, l1,
+                                                  args.cpu_steps, args.ddim_steps)
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)
