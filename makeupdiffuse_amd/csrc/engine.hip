@@ -98,7 +98,7 @@ struct Op {
 };
 
 // kinds: [0, 32) conv GEMM by tile config, [32, 64) linear GEMM by tile config, then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 32, K_GROUPNORM = 64, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 48, K_GROUPNORM = 96, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};

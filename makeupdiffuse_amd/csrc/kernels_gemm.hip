@@ -567,17 +567,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs 
 //       fewer blocks than CUs finishes sooner when each block pulls FEWER operand bytes ((TM + TN) * K * 2), not more
 //   20..29: in-block K split (KW groups of 4 waves, see gemm_kernel): 32x32 x2 / x4, 64x32 x2 / x4, 64x64 x2 / x4, 32x64 x2 / x4,
 //       128x64 x2, 64x128 x2
-constexpr int N_TILE_CFG = 30;
+//   30..37: more waves per CU pulling operands.  A 4-wave workgroup streams ~48 GB/s whatever its ring depth (2, 4 or 8 stages), a CU
+//       with 8 waves ~94 GB/s, with 16 waves ~122 GB/s (tools/micro/stream_rate2.hip): the limit is per WAVE.  So: the same tiles with
+//       2-stage rings (half the LDS -> twice the resident workgroups): 64x64, 128x64, 64x128, 64x32; and 8-wave workgroups:
+//       128x128 (2 stages), 128x64, 64x128 (3), 64x64 (4).  Plain epilogue only (anything else runs on the base configuration).
+constexpr int N_TILE_CFG = 38;
 static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32,
-                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64};
+                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64};
 static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32,
-                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128};
-static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2};
-static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4};
+                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64};
+static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1};
+static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4,
+                                          5, 3, 4, 18, 2, 3, 4, 5};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
                                                   "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32",
-                                                  "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2"};
+                                                  "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2",
+                                                  "64x64_s2", "128x64_s2", "64x128_s2", "64x32_s2", "128x128_w8", "128x64_w8", "64x128_w8", "64x64_w8"};
 static bool is_patch_cfg(int c) { return c >= 6 && c <= 11; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -704,6 +711,7 @@ static int gemm_resolve_plan(const GemmArgs& a, GemmPlan* out) {
     }
     if (a.stat_out) g = stat_producer_plan(g);
     if (kTileKW[g.cfg] > 1 && ((a.ln_s && a.stat_in) || a.stat_out || (a.gn_stat && g.splitk == 1))) g.cfg = kTileBase[g.cfg];     // plain epilogue (or on-the-fly LayerNorm) only
+    if (kTileLight[g.cfg] && (a.ln_s || a.stat_out || (a.gn_stat && g.splitk == 1))) g.cfg = kTileBase[g.cfg];                     // plain epilogue only
     if (is_patch_cfg(g.cfg) && !conv_patch_supported(a, g.cfg)) {
         if (is_patch_cfg(g_force_cfg)) return mkd_fail(-4, "gemm: forced LDS-staged conv tile does not fit this shape");
         g = gemm_plan(a.M, a.N, a.K, 0, 0, 0, 0, /*pin_cfg=*/1);
@@ -761,6 +769,24 @@ static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
     }
     if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
     else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
+    return 0;
+}
+
+// plain-epilogue-only launcher (tile configurations 30..37): two instantiations per configuration
+template <int TM, int TN, int WM, int WN, int STAGES>
+static int launch_tile_light(const GemmArgs& a, int splitk, hipStream_t stream) {
+    const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (size_t)WN * TM * 2 * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
+        hipError_t e = a.conv ? hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 1, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                              : hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, 0, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+        attr_set[a.conv ? 1 : 0] = true;
+    }
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 block(64 * WM * WN);
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, a);
     return 0;
 }
 
@@ -867,6 +893,14 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         case 27: rc = launch_tile_kw<32, 64, 2, 2, 3, 4>(a, g.splitk, stream); break;
         case 28: rc = launch_tile_kw<128, 64, 2, 2, 3, 2>(a, g.splitk, stream); break;
         case 29: rc = launch_tile_kw<64, 128, 2, 2, 3, 2>(a, g.splitk, stream); break;
+        case 30: rc = launch_tile_light<64, 64, 2, 2, 2>(a, g.splitk, stream); break;
+        case 31: rc = launch_tile_light<128, 64, 2, 2, 2>(a, g.splitk, stream); break;
+        case 32: rc = launch_tile_light<64, 128, 2, 2, 2>(a, g.splitk, stream); break;
+        case 33: rc = launch_tile_light<64, 32, 2, 2, 2>(a, g.splitk, stream); break;
+        case 34: rc = launch_tile_light<128, 128, 4, 2, 2>(a, g.splitk, stream); break;
+        case 35: rc = launch_tile_light<128, 64, 4, 2, 3>(a, g.splitk, stream); break;
+        case 36: rc = launch_tile_light<64, 128, 2, 4, 3>(a, g.splitk, stream); break;
+        case 37: rc = launch_tile_light<64, 64, 2, 4, 4>(a, g.splitk, stream); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
     }
     if (rc) return rc;

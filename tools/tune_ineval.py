@@ -27,8 +27,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64]
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24)
 KEYS = ('M', 'N', 'K', 'conv', 'stride', 'up', 'Hin', 'Win', 'Cin', 'Hout', 'Wout')
 
@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--cfgs', default=None, help='comma-separated tile configurations to try (default: all)')
     ap.add_argument('--out', default='gpurun_out/ineval.json')
     args = ap.parse_args()
     lib = mlib.load()
@@ -106,7 +107,7 @@ def main():
           f'wall {wall0:.3f} ms/eval', flush=True)
     trials = collections.defaultdict(list)
     t_start = time.time()
-    for cfg in range(len(TILE_M)):
+    for cfg in ([int(c) for c in args.cfgs.split(',')] if args.cfgs else range(len(TILE_M))):
         for s in SPLITS:
             todo = [sh for sh in shapes if valid(lib, sh, cfg, s)]
             if not todo:
