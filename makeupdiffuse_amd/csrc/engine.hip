@@ -1257,6 +1257,13 @@ struct mkd_ctx {
         run_main = stream; run_serial = !dual_stream;
         for (auto& op : plan_eps) {
             const int sid = (capturing && op.cap_sid >= 0) ? op.cap_sid : op.sid;
+#ifdef MKD_EXP_ABLATE
+            // experiment build only (tools/exp_ablate.sh): leave a whole kernel class out of the evaluation (WRONG results) to bound what
+            // any optimisation of that class could gain inside the concurrent loop.  1 GroupNorm, 2 LayerNorm, 4 attention
+            static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;
+            if (op.launches > 0 && (((skip & 1) && op.kind == K_GROUPNORM) || ((skip & 2) && op.kind == K_LAYERNORM) ||
+                                    ((skip & 4) && op.kind == K_ATTENTION))) continue;
+#endif
             int rc = op.fn(stream_of(sid));
             if (rc) return rc;
         }

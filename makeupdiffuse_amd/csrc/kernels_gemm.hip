@@ -910,6 +910,10 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
 }
 
 int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream) {
+#ifdef MKD_EXP_ABLATE
+    static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;      // experiment build only: 8 = no split-K reduce launches (WRONG results)
+    if (skip & 8) return 0;
+#endif
     if (a.gn_stat) {
         dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
         hipLaunchKernelGGL(splitk_epilogue_gn_kernel, rg, dim3(256), 0, stream, a);
