@@ -1263,6 +1263,17 @@ struct mkd_ctx {
             static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;
             if (op.launches > 0 && (((skip & 1) && op.kind == K_GROUPNORM) || ((skip & 2) && op.kind == K_LAYERNORM) ||
                                     ((skip & 4) && op.kind == K_ATTENTION))) continue;
+            // MKD_EXP_EMPTY: same classes, but the launch stays and only its work goes (a one-element fill kernel in its place):
+            // separates what a class costs as launches from what it costs as work
+            static const int empty = getenv("MKD_EXP_EMPTY") ? atoi(getenv("MKD_EXP_EMPTY")) : 0;
+            if (op.launches > 0 && (((empty & 1) && op.kind == K_GROUPNORM) || ((empty & 2) && op.kind == K_LAYERNORM) ||
+                                    ((empty & 4) && op.kind == K_ATTENTION) || ((empty & 16) && op.kind < K_GROUPNORM))) {
+                static int64_t* dummy = nullptr;
+                if (!dummy) MKD_HIP_CHECK(hipMalloc((void**)&dummy, 256));
+                int rc = launch_fill_i64(dummy, 0, 1, stream_of(sid));
+                if (rc) return rc;
+                continue;
+            }
 #endif
             int rc = op.fn(stream_of(sid));
             if (rc) return rc;

@@ -270,6 +270,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         return;
     }
     // ---- epilogue -------------------------------------------------------------------------------------------------
+    // fast form (gemm_device.h: epilogue_fast_store): bias / row bias / scale / residual -> bf16 without per-fragment branches; the
+    // rows of a wave are pixels of ONE image whenever TH * TW is a multiple of the wave's rows (wave-uniform test)
+    if (pre && epi.act == 0 && !epi.out_f32) {
+        int rb_b = -1;
+        bool ok = true;
+        if (epi.rowbias) {
+            const int pr0 = wm * (TM / WM);
+            const int img0 = pr0 / (TH * TW), img1 = (pr0 + TM / WM - 1) / (TH * TW);
+            rb_b = ((b0 + img0) * H * Wd) / epi.rpb;
+            ok = img0 == img1 && epi.rpb == H * Wd && b0 + img0 < batch;
+        }
+        if (ok) {
+            f32x4 prb[NI];
+            if (rb_b >= 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+                    prb[ni] = n < N ? *(const f32x4*)(epi.rowbias + (size_t)rb_b * epi.ldrb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = mrow[mi];
+                if (m < 0) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+                    if (n >= N) continue;
+                    if (rb_b >= 0) epilogue_fast_store<true>(epi, m, n, acc[ni][mi], pbias[ni], prb[ni], pres[ni][mi]);
+                    else epilogue_fast_store<false>(epi, m, n, acc[ni][mi], pbias[ni], pbias[ni], pres[ni][mi]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mrow[mi];

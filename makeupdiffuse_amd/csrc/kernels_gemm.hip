@@ -393,6 +393,41 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
         return;
     }
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of every (ni, mi) fragment ---------------
+    // Fast form (gemm_device.h: epilogue_fast_store) whenever the launch asks for nothing but bias / row bias / scale / residual
+    // -> bf16: wave-uniform decision (the row bias needs all rows of the wave in one sample), same arithmetic as the general form.
+    if (pre && !stat_out && epi.act == 0 && !epi.out_f32) {
+        const int wr0 = m0 + wm * (TM / WM);
+        int rb_b = -1;
+        bool ok = true;
+        if (epi.rowbias) {
+            const int wr1 = min(wr0 + TM / WM, M) - 1;
+            rb_b = wr0 / epi.rpb;
+            ok = wr1 < wr0 || rb_b == wr1 / epi.rpb;
+        }
+        if (ok) {
+            f32x4 prb[NI];
+            if (rb_b >= 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+                    prb[ni] = n < N ? *(const f32x4*)(epi.rowbias + (size_t)rb_b * epi.ldrb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = wr0 + mi * 16 + frow;
+                if (m >= M) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + wn * (TN / WN) + ni * 16 + 4 * fq;
+                    if (n >= N) continue;
+                    if (rb_b >= 0) epilogue_fast_store<true>(epi, m, n, acc[ni][mi], pbias[ni], prb[ni], pres[ni][mi]);
+                    else epilogue_fast_store<false>(epi, m, n, acc[ni][mi], pbias[ni], pbias[ni], pres[ni][mi]);
+                }
+            }
+            return;
+        }
+    }
     float* const statlds = (float*)(smem + STAGES * STAGE);        // [WN][TM][2] scratch behind the ring
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {

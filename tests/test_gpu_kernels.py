@@ -235,7 +235,11 @@ def test_conv3x3_lds_staged_tiles(cfg, B, H, W_, Cin, Cout, pad_ld, splitk):
 
 @pytest.mark.parametrize('B,hw,C,silu,eps,pad', [(2, 64, 320, 1, 1e-5, 0), (3, 256, 640, 0, 1e-6, 0), (2, 16, 2560, 1, 1e-5, 0),
                                                 (2, 1024, 320, 1, 1e-5, 0), (2, 64, 960, 1, 1e-5, 64), (2, 16, 64, 1, 1e-5, 0), (1, 4096, 960, 1, 1e-5, 0), (2, 4096, 320, 0, 1e-5, 0),
-                                                (1, 64, 1920, 1, 1e-5, 0)])
+                                                (1, 64, 1920, 1, 1e-5, 0),
+                                                # large tensors: ragged pixel counts, strided rows, every vector width
+                                                (4, 1024, 640, 1, 1e-5, 64), (4, 1024, 960, 1, 1e-5, 0), (8, 1024, 320, 1, 1e-5, 320),
+                                                (1, 1024, 2560, 0, 1e-6, 0), (3, 1600, 320, 1, 1e-5, 0), (2, 1024, 1920, 1, 1e-5, 0),
+                                                (5, 1032, 1280, 1, 1e-5, 0)])
 def test_groupnorm(B, hw, C, silu, eps, pad):
     lib = L()
     g = torch.Generator().manual_seed(C + hw)

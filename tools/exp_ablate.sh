@@ -11,3 +11,10 @@ run no_splitk_reduce MKD_EXP_SKIP=8
 run no_gn_ln_reduce MKD_EXP_SKIP=11
 run none_of_them MKD_EXP_SKIP=15
 run base2 MKD_EXP_SKIP=0
+# the launches stay, only the work goes (a one-element fill kernel in place of every kernel of the class; 16 = every GEMM / convolution)
+run empty_groupnorm MKD_EXP_EMPTY=1
+run empty_layernorm MKD_EXP_EMPTY=2
+run empty_attention MKD_EXP_EMPTY=4
+run empty_gemm MKD_EXP_EMPTY=16
+run empty_all MKD_EXP_EMPTY=23
+run base3 MKD_EXP_SKIP=0
