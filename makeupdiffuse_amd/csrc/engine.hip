@@ -95,6 +95,7 @@ struct Op {
     std::string label;
     int sid = 0;            // 0: caller's stream, 1..3: side streams, HELPER_BASE + k: helper work on side stream k
     int cap_sid = -1;       // stream while a hipGraph is being captured (-1: same)
+    int edge_from = -1, edge_to = -1; bool edge_in_graph = false;       // cross-stream edge ops (op_edge)
 };
 
 // kinds: [0, 32) conv GEMM by tile config, [32, 64) linear GEMM by tile config, then the rest
@@ -228,6 +229,19 @@ struct mkd_ctx {
     hipStream_t loop_stream = nullptr; hipEvent_t ev_loop_in = nullptr, ev_loop_out = nullptr;
     hipGraphExec_t multi_graph = nullptr; int multi_graph_steps = 0;      // MKD_GRAPH_STEPS consecutive steps as one graph
     hipGraphExec_t step_graph = nullptr; int step_graph_cfg = -1; float step_graph_scale = 0.f; int plan_generation = 0, step_graph_gen = -1;
+    // Graph mode 2 (MKD_GRAPH_MODE=2; default 1 = one captured graph per step): one step = LINEAR graphs, one per (stream, stretch
+    // between two cross-stream edges), launched on their own streams and ordered by events.  A captured graph with two BRANCHES is
+    // replayed with its branches serialised node by node (tools/micro/launch_floor.hip: 3.2 us per pair of empty nodes, 5.3-5.9 us
+    // per pair of small kernels; tools/micro/two_phase.hip: 1836 us for a 720-launch step of small kernels), two linear graphs on two
+    // streams run side by side (1.7 / 1.9-3.4 us per pair; 725 us per step).  In the real evaluation the launch floor does drop
+    // (every kernel empty: 1.65 -> 0.93 ms) but the GroupNorm / LayerNorm / attention kernels no longer hide in the dispatcher's
+    // gaps (0.09 -> 1.0 ms) and the GEMM work is 4.0 ms either way: 5.96 vs 5.75 ms per evaluation at batch 8, 3.12 vs 2.96 at
+    // batch 1 - measured, kept as a switch, off.
+    struct SegAction { int type; int sid; int idx; };      // type 0: launch seg_graphs[idx] / seg_eager[idx] on stream sid; 1: record event idx on sid; 2: sid waits for event idx
+    struct Segment { hipGraphExec_t graph = nullptr; std::vector<OpFn> eager; };
+    std::vector<Segment> segs; std::vector<SegAction> seg_actions; std::vector<hipEvent_t> seg_events;
+    int seg_gen = -1, seg_cfg = -1; float seg_scale = 0.f;
+    int graph_mode = getenv("MKD_GRAPH_MODE") ? atoi(getenv("MKD_GRAPH_MODE")) : 1;
 
     // ---------------------------------------------------------------------------------------------
     int ctx_len() const { return 77; }
@@ -1303,6 +1317,7 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipStreamWaitEvent(self->stream_of(to_sid), self->aux_ev[e], 0));
             return 0;
         }, 0, 0.0, K_MISC, "edge " + std::to_string(from_sid) + "->" + std::to_string(to_sid));
+        if (!dry) { Op& o = cur_plan->back(); o.edge_from = from_sid; o.edge_to = to_sid; o.edge_in_graph = in_graph; }
     }
 
     // one eps with a hipEvent pair around every plan op: per-kernel-class device time (bench roofline)
@@ -1336,7 +1351,110 @@ struct mkd_ctx {
         return rc;
     }
 
+    void drop_segments() {
+        for (auto& sg : segs) if (sg.graph) hipGraphExecDestroy(sg.graph);
+        segs.clear(); seg_actions.clear(); seg_gen = -1;
+    }
+    // One reverse step as per-stream linear graphs (graph mode 2).  Walks the step's launches in plan order; every cross-stream edge
+    // that the single-graph capture keeps (in_graph) closes the pending stretch of both its streams.
+    int build_segments(int batch, bool cfg_on, float cfg_scale) {
+        drop_segments();
+        const int64_t n = (int64_t)batch * cfg.in_channels * h * w;
+        mkd_ctx* self = this;
+        struct Item { OpFn fn; int sid; int from, to; };
+        std::vector<Item> items;
+        const int Bn = B;
+        items.push_back({[self, Bn](hipStream_t st) { return launch_step_setup(self->s_state, self->s_t, Bn, st); }, 0, -1, -1});
+        const float* ec; const float* eu = nullptr;
+        if (cfg_on) {
+            items.push_back({[self, n](hipStream_t st) { return launch_repeat_batch(self->s_xa, self->s_xin, n, 2, st); }, 0, -1, -1});
+            io_x = s_xin; eu = s_eps; ec = s_eps + n;
+        } else { io_x = s_xa; ec = s_eps; }
+        io_t = s_t; io_out = s_eps;
+        for (auto& op : plan_eps) {
+            if (op.edge_from >= 0) { if (op.edge_in_graph) items.push_back({nullptr, 0, arena_of(op.edge_from), arena_of(op.edge_to)}); continue; }
+            if (op.launches == 0 && op.kind == K_MISC && op.label.rfind("edge", 0) == 0) continue;
+#ifdef MKD_EXP_ABLATE
+            {   // experiment build only: the same class switches as in eps()
+                static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;
+                static const int empty = getenv("MKD_EXP_EMPTY") ? atoi(getenv("MKD_EXP_EMPTY")) : 0;
+                auto hit = [&](int m) { return op.launches > 0 && (((m & 1) && op.kind == K_GROUPNORM) || ((m & 2) && op.kind == K_LAYERNORM) ||
+                                                                    ((m & 4) && op.kind == K_ATTENTION) || ((m & 16) && op.kind < K_GROUPNORM)); };
+                if (hit(skip & 7)) continue;
+                if (hit(empty)) {
+                    static int64_t* dummy = nullptr;
+                    if (!dummy) MKD_HIP_CHECK(hipMalloc((void**)&dummy, 256));
+                    int64_t* dd = dummy;
+                    items.push_back({[dd](hipStream_t st) { return launch_fill_i64(dd, 0, 1, st); }, arena_of(op.cap_sid >= 0 ? op.cap_sid : op.sid), -1, -1});
+                    continue;
+                }
+            }
+#endif
+            items.push_back({op.fn, arena_of(op.cap_sid >= 0 ? op.cap_sid : op.sid), -1, -1});
+        }
+        items.push_back({[self, ec, eu, cfg_scale, n](hipStream_t st) { return launch_ddim_step_state(self->s_xa, ec, eu, cfg_scale, self->s_state, n, st); }, 0, -1, -1});
+        std::vector<OpFn> pend[NS];
+        int rc = 0;
+        auto flush = [&](int sid) -> int {
+            if (pend[sid].empty()) return 0;
+            Segment sg;
+            if (pend[sid].size() <= 2) sg.eager = pend[sid];
+            else {
+                hipStream_t st = stream_of(sid);
+                hipGraph_t g = nullptr;
+                MKD_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+                int r = 0;
+                for (auto& f : pend[sid]) { r = f(st); if (r) break; }
+                hipError_t e = hipStreamEndCapture(st, &g);
+                if (r) { if (g) hipGraphDestroy(g); return r; }
+                if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("hipStreamEndCapture (segment): ") + hipGetErrorString(e));
+                e = hipGraphInstantiate(&sg.graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("hipGraphInstantiate (segment): ") + hipGetErrorString(e));
+            }
+            segs.push_back(std::move(sg));
+            seg_actions.push_back({0, sid, (int)segs.size() - 1});
+            pend[sid].clear();
+            return 0;
+        };
+        int n_ev = 0;
+        capturing = true;          // (ops that look at the flag behave as in the single-graph capture)
+        for (auto& it : items) {
+            if (it.from >= 0) {
+                if (it.from == it.to) continue;
+                if ((rc = flush(it.from))) break;
+                if (n_ev == (int)seg_events.size()) {
+                    hipEvent_t e = nullptr;
+                    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = mkd_fail(MKD_ERR_HIP, "hipEventCreate (segment)"); break; }
+                    seg_events.push_back(e);
+                }
+                seg_actions.push_back({1, it.from, n_ev});
+                if ((rc = flush(it.to))) break;
+                seg_actions.push_back({2, it.to, n_ev});
+                ++n_ev;
+            } else pend[it.sid].push_back(it.fn);
+        }
+        for (int sid = NS - 1; sid >= 0 && !rc; --sid) rc = flush(sid);      // (every side stream was joined by an edge: only stream 0 has work left)
+        capturing = false;
+        if (rc) { drop_segments(); return rc; }
+        seg_gen = plan_generation; seg_cfg = (int)cfg_on; seg_scale = cfg_scale;
+        return 0;
+    }
+    int run_segments() {
+        for (auto& a : seg_actions) {
+            hipStream_t st = stream_of(a.sid);
+            if (a.type == 0) {
+                Segment& sg = segs[a.idx];
+                if (sg.graph) MKD_HIP_CHECK(hipGraphLaunch(sg.graph, st));
+                else for (auto& f : sg.eager) { int rc = f(st); if (rc) return rc; }
+            } else if (a.type == 1) MKD_HIP_CHECK(hipEventRecord(seg_events[a.idx], st));
+            else MKD_HIP_CHECK(hipStreamWaitEvent(st, seg_events[a.idx], 0));
+        }
+        return 0;
+    }
+
     void drop_graph() {
+        drop_segments();
         if (step_graph) { hipGraphExecDestroy(step_graph); step_graph = nullptr; }
         if (multi_graph) { hipGraphExecDestroy(multi_graph); multi_graph = nullptr; multi_graph_steps = 0; }
         step_graph_gen = -1;
@@ -1392,6 +1510,17 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipEventRecord(ev_loop_in, stream));
             MKD_HIP_CHECK(hipStreamWaitEvent(loop_stream, ev_loop_in, 0));
             MKD_HIP_CHECK(hipMemcpyAsync(s_state, h_state, sizeof(StepState), hipMemcpyHostToDevice, loop_stream));
+            if (graph_mode == 2 && dual_stream) {
+                run_main = loop_stream; run_serial = false;
+                if (segs.empty() || seg_gen != plan_generation || seg_cfg != (int)cfg_on || seg_scale != cfg_scale) {
+                    int rc = build_segments(batch, cfg_on, cfg_scale); if (rc) return rc;
+                }
+                for (int i = 0; i < n_steps; ++i) { int rc = run_segments(); if (rc) return rc; }
+                MKD_HIP_CHECK(hipMemcpyAsync(x_out, s_xa, n * sizeof(float), hipMemcpyDeviceToDevice, loop_stream));
+                MKD_HIP_CHECK(hipEventRecord(ev_loop_out, loop_stream));
+                MKD_HIP_CHECK(hipStreamWaitEvent(stream, ev_loop_out, 0));
+                return 0;
+            }
             if (!step_graph || step_graph_gen != plan_generation || step_graph_cfg != (int)cfg_on || step_graph_scale != cfg_scale) {
                 drop_graph();
                 hipGraph_t g = nullptr;
@@ -1838,6 +1967,7 @@ struct mkd_ctx {
         for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
         for (hipEvent_t e : aux_ev) hipEventDestroy(e);
+        for (hipEvent_t e : seg_events) hipEventDestroy(e);
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
         if (h_state) hipHostFree(h_state);
         if (s_state) hipFree(s_state);

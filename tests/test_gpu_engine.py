@@ -339,3 +339,31 @@ def test_layernorm_on_the_fly_plans_match_golden(mask, monkeypatch):
     check_eps(a, G['x5'], rel=1.5e-2, cos=0.9999, what=f'5-step latent, MKD_LN_FLY={mask}')
     assert torch.equal(a, b)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lanes', [0, 2])
+def test_linear_graph_segments_equal_the_eager_loop(lanes, monkeypatch):
+    """MKD_GRAPH_MODE=2: a step replayed as per-stream LINEAR graphs ordered by events (instead of one captured graph with branches)
+    gives the eager loop's latents bit for bit - plain and with guidance, cached segments re-used, with and without decoder lanes."""
+    monkeypatch.setenv('MKD_GRAPH_MODE', '2')
+    monkeypatch.setenv('MKD_DEC_LANES', str(lanes))
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.load_state_dict(sd)
+    G = {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
+    sch = sampler.Schedule().make_ddim(5)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    eng.prepare(G['hint'], G['ctx'])
+    a = eng.sample(G['x'], *args, use_graph=False)
+    b = eng.sample(G['x'], *args, use_graph=True)
+    c = eng.sample(G['x'], *args, use_graph=True)          # cached segments
+    check_eps(a, G['x5'], rel=1.5e-2, cos=0.9999, what='5-step latent, linear graph segments')
+    assert torch.equal(a, b) and torch.equal(a, c)
+    eng.prepare(torch.cat([G['hint'], G['hint']]), torch.cat([G['uctx'], G['ctx']]))
+    d = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=False)
+    e = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=True)
+    assert torch.equal(d, e)
+    eng.close()

@@ -102,6 +102,26 @@ int main() {
         static const char* names[5] = {"empty <<<1,64>>>", "empty <<<256,256>>>", "one line in, one out per WG (256 WGs)", "5 MB in -> 5 MB out, 1024 WGs", "320 KB in -> out, 64 WGs"};
         printf("two linear graphs on two streams, %d nodes each: %-38s %6.2f us per node (pair)\n", N, names[mode], best * 1e3 / N);
     }
+    // what a graph BOUNDARY costs: the 400-node chain of 5 MB passes as 1, 4, 16 graphs launched back to back on one stream
+    for (int parts : {1, 4, 16}) {
+        const int per = N / parts;
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < per; ++i) hipLaunchKernelGGL(k_pass, dim3(1024), dim3(256), 0, s0, (const float4*)((i & 1) ? b : a), (float4*)((i & 1) ? a : b), n4);
+        CK(hipStreamEndCapture(s0, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int k = 0; k < parts; ++k) CK(hipGraphLaunch(ge, s0));
+        CK(hipStreamSynchronize(s0));
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            CK(hipEventRecord(e0, s0));
+            for (int k = 0; k < parts; ++k) CK(hipGraphLaunch(ge, s0));
+            CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+        }
+        printf("one chain of %d 5 MB passes as %2d graph launches: %7.1f us total, %5.2f us per node\n", per * parts, parts, best * 1e3, best * 1e3 / (per * parts));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    }
     // no graph at all: eager launches on two streams
     for (int mode = 0; mode < 5; mode += 3) {
         float best = 1e9f;
