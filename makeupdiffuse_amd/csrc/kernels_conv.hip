@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         // ---- epilogue with GroupNorm statistics (as in gemm_kernel; tile row = local pixel index, one segment per image) ----
         constexpr int GTS = TN + 4;
         constexpr int GTILE = (TM * GTS * 2 + 15) & ~15;
-        constexpr int LDS_MIN = 2 * 4 * NW * 1024 + STAGES * WSB + GACCB;            // smallest patch slot (PP >= 4)
+        constexpr int LDS_MIN = 2 * PP * NW * 1024 + STAGES * WSB + GACCB;
         static_assert(GTILE + 64 * 16 <= LDS_MIN, "GroupNorm statistics tile must fit in the staging buffers");
         uint16_t* const gtile = (uint16_t*)smem;
         if (!gfast) __syncthreads();
@@ -340,6 +340,10 @@ int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 
 template <int TM, int TN, int WM, int WN>
 int launch_patch_pp(const GemmArgs& a, int pp, dim3 grid, hipStream_t stream) {
+    if constexpr (WM * WN == 8 && TM <= 128) {          // 8 waves on a 64- / 128-pixel tile: 2 or 3 pieces per wave hold the patch
+        if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream);
+        if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream);
+    }
     if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream);
     if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream);
     if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream);
@@ -363,19 +367,33 @@ bool conv_patch_geometry(int tm, int batch, int H, int W, int* th, int* tw, int*
     const int np = IM * (TH + 2) * (TW + 2);
     int pp = ((np + 7) / 8 + nwaves - 1) / nwaves;
     if (pp > 9) return false;
-    if (pp < 4) pp = 4;
+    const int pp_min = (nwaves == 8 && tm <= 128) ? 2 : 4;
+    if (pp < pp_min) pp = pp_min;
     if (pp == 8) pp = 9;
     *th = TH; *tw = TW; *imgs = IM; *pieces_per_wave = pp;
     return true;
 }
 
-// cfg: 6: 256x128 (8 waves), 7: 256x64 (8 waves), 8: 128x128, 9: 128x64, 10: 64x128, 11: 64x64 (4 waves)
+// cfg: 6: 256x128 (8 waves), 7: 256x64 (8 waves), 8: 128x128, 9: 128x64, 10: 64x128, 11: 64x64 (4 waves);
+// 38: 128x64, 39: 64x128, 40: 128x128 with EIGHT waves (32x32 / 32x32 / 32x64 per wave): a wave's LDS-DMA transfers complete one
+// after the other (~1 KiB per 200-300 cycles, tools/micro/stream_rate3.hip), and with four waves each tap asks 2.7 pieces of every
+// wave for 16 MFMAs - the tap waits for the transfers, not for the matrix cores; eight waves halve the pieces per wave
+static bool patch_cfg_shape(int cfg, int* tm, int* tn, int* nw) {
+    static const int tms[9] = {256, 256, 128, 128, 64, 64, 128, 64, 128};
+    static const int tns[9] = {128, 64, 128, 64, 128, 64, 64, 128, 128};
+    static const int nws[9] = {8, 8, 4, 4, 4, 4, 8, 8, 8};
+    int i;
+    if (cfg >= 6 && cfg <= 11) i = cfg - 6;
+    else if (cfg >= 38 && cfg <= 40) i = cfg - 38 + 6;
+    else return false;
+    *tm = tms[i]; *tn = tns[i]; *nw = nws[i];
+    return true;
+}
+
 bool conv_patch_supported(const GemmArgs& a, int cfg) {
     if (!a.conv || a.stride != 1 || a.up != 0 || a.Cin % 64 || a.Hin != a.Hout || a.Win != a.Wout) return false;
-    static const int tms[6] = {256, 256, 128, 128, 64, 64};
-    static const int tns[6] = {128, 64, 128, 64, 128, 64};
-    if (cfg < 6 || cfg > 11) return false;
-    const int tm = tms[cfg - 6], tn = tns[cfg - 6], nw = tm == 256 ? 8 : 4;
+    int tm, tn, nw;
+    if (!patch_cfg_shape(cfg, &tm, &tn, &nw)) return false;
     int th, tw, im, pp;
     if (!conv_patch_geometry(tm, a.M / (a.Hin * a.Win), a.Hin, a.Win, &th, &tw, &im, &pp, nw)) return false;
     const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)3 * tn * 128 + (a.gn_stat ? 4096 : 0);
@@ -384,9 +402,8 @@ bool conv_patch_supported(const GemmArgs& a, int cfg) {
 
 int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
     if (!conv_patch_supported(a, cfg)) return mkd_fail(-4, "conv3x3_patch: unsupported shape for this tile");
-    static const int tms[6] = {256, 256, 128, 128, 64, 64};
-    static const int tns[6] = {128, 64, 128, 64, 128, 64};
-    const int tm = tms[cfg - 6], tn = tns[cfg - 6], nw = tm == 256 ? 8 : 4;
+    int tm, tn, nw;
+    patch_cfg_shape(cfg, &tm, &tn, &nw);
     const int batch = a.M / (a.Hin * a.Win);
     int pp;
     conv_patch_geometry(tm, batch, a.Hin, a.Win, &a.tile_h, &a.tile_w, &a.tile_imgs, &pp, nw);
@@ -408,6 +425,9 @@ int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
         case 8: rc = launch_patch_pp<128, 128, 2, 2>(a, pp, grid, stream); break;
         case 9: rc = launch_patch_pp<128, 64, 2, 2>(a, pp, grid, stream); break;
         case 10: rc = launch_patch_pp<64, 128, 2, 2>(a, pp, grid, stream); break;
+        case 38: rc = launch_patch_pp<128, 64, 4, 2>(a, pp, grid, stream); break;
+        case 39: rc = launch_patch_pp<64, 128, 2, 4>(a, pp, grid, stream); break;
+        case 40: rc = launch_patch_pp<128, 128, 4, 2>(a, pp, grid, stream); break;
         default: rc = launch_patch_pp<64, 64, 2, 2>(a, pp, grid, stream); break;
     }
     if (rc) return rc;

@@ -36,7 +36,7 @@ def main():
         t_def = T.time_cfg(lib, shape, -1, 0, pool, A, out)
         trials = []
         for cfg in range(len(T.TILE_M)):
-            patch = 6 <= cfg <= 11
+            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40
             tiles = -(-M // T.TILE_M[cfg]) * -(-N // T.TILE_N[cfg])
             units = Cin // 64 if patch else (K + 63) // 64
             for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
@@ -49,8 +49,8 @@ def main():
         gf = 2.0 * M * N * K / 1e9
         print(f'M={M} N={N} K={K} {Hin}x{Win}: table {t_def:.1f} us ({gf / t_def * 1e-3:.0f} TF/s)')
         for t, cfg, s, wgs in trials[:topn]:
-            print(f'    cfg {cfg:2d} ({T.TILE_M[cfg]}x{T.TILE_N[cfg]}{" patch" if 6 <= cfg <= 11 else ""}) splitk {s:2d} workgroups {wgs:4d}: {t:6.1f} us  {gf / t * 1e-3:5.0f} TF/s')
-        best_patch = [x for x in trials if 6 <= x[1] <= 11][:3]
+            print(f'    cfg {cfg:2d} ({T.TILE_M[cfg]}x{T.TILE_N[cfg]}{" patch" if (6 <= cfg <= 11 or 38 <= cfg <= 40) else ""}) splitk {s:2d} workgroups {wgs:4d}: {t:6.1f} us  {gf / t * 1e-3:5.0f} TF/s')
+        best_patch = [x for x in trials if 6 <= x[1] <= 11 or 38 <= x[1] <= 40][:3]
         for t, cfg, s, wgs in best_patch:
             print(f'    best patch: cfg {cfg} splitk {s} workgroups {wgs}: {t:.1f} us')
         sys.stdout.flush()

@@ -26,8 +26,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128]
 KEYS = ('M', 'N', 'K', 'conv', 'stride', 'up', 'Hin', 'Win', 'Cin', 'Hout', 'Wout', 'splitk')
 
 
@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--min-us', type=float, default=40.0, help='only shapes with at least this much serial time per evaluation')
     ap.add_argument('--gain', type=float, default=0.003, help='relative wall-time gain a change must show (twice) to be kept')
     ap.add_argument('--budget-s', type=float, default=600.0)
+    ap.add_argument('--cfgs', default=None, help='comma list: only these tile configurations are candidates')
+    ap.add_argument('--skip', type=int, default=0, help='start at this shape (shapes are ordered by their serial time)')
     ap.add_argument('--out', default='gpurun_out/wall.json')
     args = ap.parse_args()
     lib = mlib.load()
@@ -78,16 +80,19 @@ def main():
     print(f'{len(shapes)} GEMM shapes, {len(order)} with >= {args.min_us} us per evaluation; wall {cur:.4f} ms/eval', flush=True)
     t_start = time.time()
     kept = {}
+    only = [int(c) for c in args.cfgs.split(',')] if args.cfgs else None
     for si, sh in enumerate(order):
+        if si < args.skip:
+            continue
         if time.time() - t_start > args.budget_s:
             print('time budget reached', flush=True)
             break
         M, N, K, conv, stride, up, Hin, Win, Cin, Hout, Wout, sk = sh
         cands = []
-        for cfg in range(len(TILE_M)):
+        for cfg in (only if only else range(len(TILE_M))):
             if not lib.mkd_gemm_cfg_supported(cfg, M, N, K, conv, Hin, Win, Cin, Hout, Wout, stride, up):
                 continue
-            patch = 6 <= cfg <= 11
+            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40
             if patch and not (conv and stride == 1 and up == 0 and Cin % 64 == 0):
                 continue
             tiles = -(-M // TILE_M[cfg]) * -(-N // TILE_N[cfg])
