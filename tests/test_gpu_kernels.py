@@ -46,7 +46,7 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41])
 @pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1), (256, 1280, 1280, 1), (96, 320, 200, 1)])
 def test_gemm_every_tile_config(cfg, M, N, K, splitk):
     """each gather-GEMM tile / pipeline-depth configuration, incl. K not a multiple of 64 and ragged M/N."""
@@ -145,7 +145,7 @@ def test_gemm_epilogue_variants():
     assert (out[:, N:] == 0).all()
 
 
-@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37])
+@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up', [(2, 16, 16, 64, 320, 1, 0), (1, 8, 8, 128, 160, 1, 1), (2, 12, 20, 32, 96, 2, 0)])
 def test_gemm_conv3x3_160_wide_tiles(cfg, B, H, W_, Cin, Cout, stride, up):
     lib = L()
