@@ -397,12 +397,13 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
     // -> bf16: wave-uniform decision (the row bias needs all rows of the wave in one sample), same arithmetic as the general form.
     if (pre && !stat_out && epi.act == 0 && !epi.out_f32) {
         const int wr0 = m0 + wm * (TM / WM);
+        if (wr0 >= M) return;                      // this wave owns no row (ragged last tile): nothing to store, no row bias to fetch
         int rb_b = -1;
         bool ok = true;
         if (epi.rowbias) {
             const int wr1 = min(wr0 + TM / WM, M) - 1;
             rb_b = wr0 / epi.rpb;
-            ok = wr1 < wr0 || rb_b == wr1 / epi.rpb;
+            ok = rb_b == wr1 / epi.rpb;
         }
         if (ok) {
             f32x4 prb[NI];

@@ -122,6 +122,28 @@ def test_gemm_fused_layernorm_chain(M, d, N2, cfg):
     assert_close_bf16(out, ref, rel=8e-3, what='fused layernorm gemm')
 
 
+@pytest.mark.parametrize('cfg', [0, 1, 3, 5, 14, 19, 21, 24, 34, 36, 41])
+@pytest.mark.parametrize('M,rpb', [(300, 20), (300, 100), (520, 64), (96, 16)])
+def test_gemm_row_bias_on_ragged_and_straddling_tiles(cfg, M, rpb):
+    """bias + per-sample row bias + scale + residual (the straight-line epilogue when all rows of a wave lie in one sample, the general
+    one otherwise): samples that end inside a tile / inside a wave, a ragged last tile whose trailing waves own no row at all."""
+    lib = L()
+    g = torch.Generator().manual_seed(cfg * 13 + M + rpb)
+    N, K = 320, 192
+    A = bf(torch.randn(M, K, generator=g)); W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g).to(DEV)
+    nb = (M + rpb - 1) // rpb
+    rowbias = torch.randn(nb, N, generator=g).to(DEV)          # EXACTLY nb rows: a read past the last sample leaves the allocation
+    R = bf(torch.randn(M, N, generator=g))
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        out = gemm(A, W, bias=bias, rowbias=rowbias, rpb=rpb, R=R, scale=0.75)
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    ref = (A.float() @ W.float().t() + bias + rowbias.repeat_interleave(rpb, 0)[:M]) * 0.75 + R.float()
+    assert_close_bf16(out, ref, what=f'row bias, cfg {cfg}, M {M}, rows per sample {rpb}')
+
+
 def test_gemm_epilogue_variants():
     g = torch.Generator().manual_seed(7)
     M, N, K, rpb = 512, 640, 640, 128
