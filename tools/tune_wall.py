@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--min-us', type=float, default=40.0, help='only shapes with at least this much serial time per evaluation')
     ap.add_argument('--gain', type=float, default=0.003, help='relative wall-time gain a change must show (twice) to be kept')
     ap.add_argument('--budget-s', type=float, default=600.0)
+    ap.add_argument('--interp', type=int, default=0, help='makeup interpolation sweep: --batch sources x this many alpha points (BASELINE config 5)')
     ap.add_argument('--cfgs', default=None, help='comma list: only these tile configurations are candidates')
     ap.add_argument('--skip', type=int, default=0, help='start at this shape (shapes are ordered by their serial time)')
     ap.add_argument('--out', default='gpurun_out/wall.json')
@@ -48,14 +49,17 @@ def main():
     eng = MkdEngine(NetConfig()); eng.init_random(0)
     g = torch.Generator().manual_seed(0)
     h = args.res // 8
-    hint = torch.rand(args.batch, 6, args.res, args.res, generator=g).cuda()
-    ctx = torch.randn(args.batch, 77, 768, generator=g).cuda()
-    x = torch.randn(args.batch, 4, h, h, generator=g).cuda()
-    t = torch.full((args.batch,), 500).cuda()
+    nb = args.batch * max(1, args.interp)
+    hint = torch.rand(nb, 6, args.res, args.res, generator=g).cuda()
+    ctx = torch.randn(nb, 77, 768, generator=g).cuda()
+    x = torch.randn(nb, 4, h, h, generator=g).cuda()
+    t = torch.full((nb,), 500).cuda()
+    hint2 = torch.rand(nb, 6, args.res, args.res, generator=g).cuda() if args.interp else None
+    alpha = torch.linspace(0.0, 1.0, args.interp).repeat(args.batch).cuda() if args.interp else None
     sch = DDIMSchedule().make_ddim(args.steps)
 
     def wall(reps=args.reps):
-        eng.prepare(hint, ctx)
+        eng.prepare(hint, ctx, hint2=hint2, alpha=alpha) if args.interp else eng.prepare(hint, ctx)
         best = 1e9
         for _ in range(reps + 1):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -65,7 +69,7 @@ def main():
         return best
 
     lib.mkd_gemm_set_override(0, 0, 0, 0, 0, 0, -1, 0)
-    eng.prepare(hint, ctx)
+    eng.prepare(hint, ctx, hint2=hint2, alpha=alpha) if args.interp else eng.prepare(hint, ctx)
     eng.eps_profile(x, t, csv_path='/tmp/wall_ops.csv')
     shapes = collections.OrderedDict()
     for r in csv.DictReader(open('/tmp/wall_ops.csv')):
