@@ -2084,7 +2084,7 @@ int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, 
 }
 int mkd_gemm_cfg_supported(int cfg, int M, int N, int K, int conv3x3, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up) {
     if (cfg < 0 || cfg >= gemm_num_tile_cfgs()) return 0;
-    if (!((cfg >= 6 && cfg <= 11) || (cfg >= 38 && cfg <= 40))) return 1;          // (only the LDS-staged conv tiles depend on the geometry)
+    if (!((cfg >= 6 && cfg <= 11) || (cfg >= 38 && cfg <= 40) || cfg == 42 || cfg == 43)) return 1;          // (only the LDS-staged conv tiles depend on the geometry)
     GemmArgs a; memset(&a, 0, sizeof(a));
     a.M = M; a.N = N; a.K = K; a.conv = conv3x3; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.stride = stride; a.up = up;
     return conv_patch_supported(a, cfg) ? 1 : 0;

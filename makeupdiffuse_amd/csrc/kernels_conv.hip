@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     constexpr int MI = TM / WM / 16;
     constexpr int PSLOT = PP * NW * 1024;    // bytes of one patch slot (PP pieces per wave)
     constexpr int WSB = TN * 128;
-    static_assert(WP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8) && STAGES >= 2 && STAGES <= 4, "layout");
+    static_assert(WP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8 || NW == 16) && STAGES >= 2 && STAGES <= 4, "layout");
 
     const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
     const int lda = p.lda, ldw = p.ldw, M = p.M, N = p.N;
@@ -340,16 +340,22 @@ int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 
 template <int TM, int TN, int WM, int WN>
 int launch_patch_pp(const GemmArgs& a, int pp, dim3 grid, hipStream_t stream) {
-    if constexpr (WM * WN == 8 && TM <= 128) {          // 8 waves on a 64- / 128-pixel tile: 2 or 3 pieces per wave hold the patch
+    if constexpr (WM * WN == 16) {                      // 16 waves: 2 or 3 pieces per wave hold a 256- / 128-pixel patch
         if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream);
         if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream);
+        return mkd_fail(-4, "conv3x3_patch: patch too large for the 16-wave tile");
+    } else {
+        if constexpr (WM * WN == 8 && TM <= 128) {      // 8 waves on a 64- / 128-pixel tile: 2 or 3 pieces per wave hold the patch
+            if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream);
+            if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream);
+        }
+        if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream);
+        if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream);
+        if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream);
+        if (pp == 7) return launch_patch<TM, TN, WM, WN, 7>(a, grid, stream);
+        if (pp <= 9) return launch_patch<TM, TN, WM, WN, 9>(a, grid, stream);
+        return mkd_fail(-4, "conv3x3_patch: patch too large");
     }
-    if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream);
-    if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream);
-    if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream);
-    if (pp == 7) return launch_patch<TM, TN, WM, WN, 7>(a, grid, stream);
-    if (pp <= 9) return launch_patch<TM, TN, WM, WN, 9>(a, grid, stream);
-    return mkd_fail(-4, "conv3x3_patch: patch too large");
 }
 
 }  // namespace
@@ -367,8 +373,9 @@ bool conv_patch_geometry(int tm, int batch, int H, int W, int* th, int* tw, int*
     const int np = IM * (TH + 2) * (TW + 2);
     int pp = ((np + 7) / 8 + nwaves - 1) / nwaves;
     if (pp > 9) return false;
-    const int pp_min = (nwaves == 8 && tm <= 128) ? 2 : 4;
+    const int pp_min = ((nwaves == 8 && tm <= 128) || nwaves == 16) ? 2 : 4;
     if (pp < pp_min) pp = pp_min;
+    if (nwaves == 16 && pp > 3) return false;
     if (pp == 8) pp = 9;
     *th = TH; *tw = TW; *imgs = IM; *pieces_per_wave = pp;
     return true;
@@ -379,12 +386,13 @@ bool conv_patch_geometry(int tm, int batch, int H, int W, int* th, int* tw, int*
 // after the other (~1 KiB per 200-300 cycles, tools/micro/stream_rate3.hip), and with four waves each tap asks 2.7 pieces of every
 // wave for 16 MFMAs - the tap waits for the transfers, not for the matrix cores; eight waves halve the pieces per wave
 static bool patch_cfg_shape(int cfg, int* tm, int* tn, int* nw) {
-    static const int tms[9] = {256, 256, 128, 128, 64, 64, 128, 64, 128};
-    static const int tns[9] = {128, 64, 128, 64, 128, 64, 64, 128, 128};
-    static const int nws[9] = {8, 8, 4, 4, 4, 4, 8, 8, 8};
+    static const int tms[11] = {256, 256, 128, 128, 64, 64, 128, 64, 128, 256, 128};
+    static const int tns[11] = {128, 64, 128, 64, 128, 64, 64, 128, 128, 128, 128};
+    static const int nws[11] = {8, 8, 4, 4, 4, 4, 8, 8, 8, 16, 16};
     int i;
     if (cfg >= 6 && cfg <= 11) i = cfg - 6;
     else if (cfg >= 38 && cfg <= 40) i = cfg - 38 + 6;
+    else if (cfg >= 42 && cfg <= 43) i = cfg - 42 + 9;          // 42: 256x128, 43: 128x128 with SIXTEEN waves (32x64 / 32x32 per wave)
     else return false;
     *tm = tms[i]; *tn = tns[i]; *nw = nws[i];
     return true;
@@ -428,6 +436,8 @@ int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
         case 38: rc = launch_patch_pp<128, 64, 4, 2>(a, pp, grid, stream); break;
         case 39: rc = launch_patch_pp<64, 128, 2, 4>(a, pp, grid, stream); break;
         case 40: rc = launch_patch_pp<128, 128, 4, 2>(a, pp, grid, stream); break;
+        case 42: rc = launch_patch_pp<256, 128, 8, 2>(a, pp, grid, stream); break;
+        case 43: rc = launch_patch_pp<128, 128, 4, 4>(a, pp, grid, stream); break;
         default: rc = launch_patch_pp<64, 64, 2, 2>(a, pp, grid, stream); break;
     }
     if (rc) return rc;

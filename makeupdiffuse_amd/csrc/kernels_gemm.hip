@@ -608,24 +608,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs 
 //       2-stage rings (half the LDS -> twice the resident workgroups): 64x64, 128x64, 64x128, 64x32; and 8-wave workgroups:
 //       128x128 (2 stages), 128x64, 64x128 (3), 64x64 (4).  Plain epilogue only (anything else runs on the base configuration).
 //   38..40: LDS-staged 3x3 conv tiles with EIGHT waves (kernels_conv.hip): 128x64, 64x128, 128x128; 41: 256x64 with 8 waves (gather /
-//       linear, plain epilogue only).  Inside the sampling loop the whole-loop tuner (tools/tune_wall.py) moves the heavy shapes onto the
+//       linear, plain epilogue only); 42 / 43: LDS-staged 256x128 / 128x128 with SIXTEEN waves.  Inside the sampling loop the whole-loop tuner (tools/tune_wall.py) moves the heavy shapes onto the
 //       eight-wave tiles although they are not faster alone: half the LDS-DMA pieces per wave and K-step.
-constexpr int N_TILE_CFG = 42;
+constexpr int N_TILE_CFG = 44;
 static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32,
-                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256};
+                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128};
 static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32,
-                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64};
-static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1};
+                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128};
+static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0};
 static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4,
-                                          5, 3, 4, 18, 2, 3, 4, 5, 38, 39, 40, 3};
+                                          5, 3, 4, 18, 2, 3, 4, 5, 38, 39, 40, 3, 42, 43};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
                                                   "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32",
                                                   "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2",
                                                   "64x64_s2", "128x64_s2", "64x128_s2", "64x32_s2", "128x128_w8", "128x64_w8", "64x128_w8", "64x64_w8",
-                                                  "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8"};
-static bool is_patch_cfg(int c) { return (c >= 6 && c <= 11) || (c >= 38 && c <= 40); }
+                                                  "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8", "patch256x128_w16", "patch128x128_w16"};
+static bool is_patch_cfg(int c) { return (c >= 6 && c <= 11) || (c >= 38 && c <= 40) || c == 42 || c == 43; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
 

@@ -219,7 +219,7 @@ def test_gemm_conv3x3(B, H, W_, Cin, Cout, stride, up, pad_ld, splitk):
     assert_close_bf16(out, ref, what='conv3x3')
 
 
-@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 38, 39, 40])
+@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 38, 39, 40, 42, 43])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,pad_ld,splitk', [(2, 32, 32, 64, 128, 0, 1), (8, 4, 4, 1280, 1280, 0, 5), (3, 8, 8, 320, 320, 64, 1),
                                                           (2, 16, 16, 128, 64, 0, 2), (1, 32, 32, 320, 320, 0, 1), (8, 8, 8, 640, 1280, 0, 3),
                                                           (5, 4, 4, 128, 192, 0, 1), (2, 64, 64, 64, 64, 0, 1)])
@@ -514,7 +514,7 @@ def test_gemm_epilogue_emits_groupnorm_statistics(cfg, B, hw, N, K, cg, coff, sp
     assert (res[0][0].cpu()[:, ~used] == 0).all()
 
 
-@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 3, 5, 25, 38, 40])
+@pytest.mark.parametrize('cfg', [6, 7, 8, 9, 10, 11, 3, 5, 25, 38, 40, 42])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,cg,coff,splitk', [(2, 32, 32, 64, 320, 10, 0, 1), (8, 4, 4, 128, 1280, 40, 0, 2), (3, 8, 8, 320, 640, 30, 320, 1),
                                                            (5, 4, 4, 128, 192, 6, 0, 1), (2, 16, 16, 128, 64, 2, 0, 2)])
 def test_conv_epilogue_emits_groupnorm_statistics(cfg, B, H, W_, Cin, Cout, cg, coff, splitk):

@@ -36,7 +36,7 @@ def main():
         t_def = T.time_cfg(lib, shape, -1, 0, pool, A, out)
         trials = []
         for cfg in range(len(T.TILE_M)):
-            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40
+            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40 or cfg in (42, 43)
             tiles = -(-M // T.TILE_M[cfg]) * -(-N // T.TILE_N[cfg])
             units = Cin // 64 if patch else (K + 63) // 64
             for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):

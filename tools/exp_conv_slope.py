@@ -17,7 +17,7 @@ def main():
     lib = mlib.load()
     pool = torch.randn(T.POOL_BYTES // 2, device=T.DEV, dtype=torch.bfloat16) * 0.02
     for (B, H, N) in ((8, 32, 320), (32, 32, 320), (8, 32, 64), (8, 16, 640)):
-        for cfg in (9, 38, 7, 10, 39, 8, 40, 36):
+        for cfg in (9, 38, 6, 42, 8, 40, 43, 36):
             pts = []
             for cin in (64, 320, 640, 1280, 2560):
                 M, K = B * H * H, 9 * cin

@@ -26,8 +26,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128]
 KEYS = ('M', 'N', 'K', 'conv', 'stride', 'up', 'Hin', 'Win', 'Cin', 'Hout', 'Wout', 'splitk')
 
 
@@ -96,7 +96,7 @@ def main():
         for cfg in (only if only else range(len(TILE_M))):
             if not lib.mkd_gemm_cfg_supported(cfg, M, N, K, conv, Hin, Win, Cin, Hout, Wout, stride, up):
                 continue
-            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40
+            patch = 6 <= cfg <= 11 or 38 <= cfg <= 40 or cfg in (42, 43)
             if patch and not (conv and stride == 1 and up == 0 and Cin % 64 == 0):
                 continue
             tiles = -(-M // TILE_M[cfg]) * -(-N // TILE_N[cfg])
