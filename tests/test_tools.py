@@ -49,3 +49,30 @@ def test_committed_table_matches_its_sources():
     have = strip(open(os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc', 'gemm_tuned.inc')).read())
     want = strip(open('/tmp/_mkd_table_check.inc').read())
     assert have == want
+
+
+def test_tuner_scripts_know_the_librarys_tile_table():
+    """tools/tune_*.py carry their own copies of the tile sizes (candidate filtering, reports): they must match kTileM / kTileN of
+    kernels_gemm.hip entry for entry, and treat the same configurations as LDS-staged conv tiles as is_patch_cfg does."""
+    import ast
+    import re
+    src = open(os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc', 'kernels_gemm.hip')).read()
+
+    def c_array(name):
+        body = re.search(r'static const int ' + name + r'\[N_TILE_CFG\] = \{([^}]*)\}', src).group(1)
+        return [int(v) for v in body.replace('\n', ' ').split(',')]
+    n = int(re.search(r'constexpr int N_TILE_CFG = (\d+);', src).group(1))
+    tm, tn = c_array('kTileM'), c_array('kTileN')
+    assert len(tm) == n and len(tn) == n and len(c_array('kTileKW')) == n and len(c_array('kTileLight')) == n and len(c_array('kTileBase')) == n
+    names = re.search(r'kTileName\[N_TILE_CFG\] = \{(.*?)\};', src, re.S).group(1)
+    assert len(re.findall(r'"[^"]+"', names)) == n
+    patch_c = re.search(r'static bool is_patch_cfg\(int c\) \{ return (.*?); \}', src).group(1)
+    is_patch = lambda c: eval(patch_c.replace('&&', ' and ').replace('||', ' or '), {'c': c})
+    for script in ('tune_gemm.py', 'tune_ineval.py', 'tune_wall.py'):
+        text = open(os.path.join(ROOT, 'tools', script)).read()
+        for var, want in (('TILE_M', tm), ('TILE_N', tn)):
+            got = ast.literal_eval(re.search(r'^' + var + r' = (\[.*\])$', text, re.M).group(1))
+            assert got == want, f'{script}: {var} differs from the library table'
+        expr = re.search(r'patch = (.*)$', text, re.M).group(1)
+        for cfg in range(n):
+            assert bool(eval(expr, {'cfg': cfg})) == bool(is_patch(cfg)), f'{script}: configuration {cfg} patch / gather mismatch'
