@@ -712,6 +712,10 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
         if (!n128 && cfg == 1) cfg = 3;
         if (cfg == 3 && tiles(3) < want && n128) cfg = 5;
         if (M <= 64) cfg = 5;
+        // shapes the tuned table does not know: the eight-wave siblings of the middle tiles (the whole-loop tuner moved most heavy
+        // shapes onto eight-wave tiles: DESIGN.md 4.4); launches that need more than the plain epilogue fall back to kTileBase
+        static const bool heur_w8 = getenv("MKD_HEUR_W8") ? atoi(getenv("MKD_HEUR_W8")) != 0 : true;      // (batch 6: +4.7 %, batch 12: +10.7 %, batch 3: +1.4 % images/s)
+        if (heur_w8 && M >= 256) cfg = cfg == 1 ? 34 : (cfg == 3 ? 35 : (cfg == 5 ? 37 : cfg));
     }
     int s = 1;
     if (force_splitk > 0) s = force_splitk;
