@@ -637,6 +637,8 @@ static const TunedEntry kTuned[] = {
     {0, 0, 0, 0, 0, 0, 0, 0}};
 
 static const TunedEntry* tuned_lookup(int M, int N, int K, int conv, int stride, int up) {
+    static const bool no_table = getenv("MKD_NO_TABLE") && atoi(getenv("MKD_NO_TABLE")) != 0;      // experiments: heuristic plans only
+    if (no_table) return nullptr;
     for (const TunedEntry* e = kTuned; e->M; ++e)
         if (e->M == M && e->N == N && e->K == K && e->conv == conv && e->stride == stride && e->up == up) return e;
     return nullptr;
