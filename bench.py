@@ -289,7 +289,8 @@ def main():
             'roofline': roofline,
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
-                     'launches_per_eval': eng.eps_launches(), 'device_gb': eng.device_bytes() / 1e9,
+                     'launches_per_eval': eng.step_launches(), 'launches_per_standalone_eps': eng.eps_launches(),
+                     'device_gb': eng.device_bytes() / 1e9,
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
                      'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None},
             'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items() if v['ms'] > 0},

@@ -163,6 +163,9 @@ int mkd_clip_encode(mkd_ctx* ctx, const int32_t* tokens, int batch, int n_tokens
 double  mkd_eps_flops(const mkd_ctx* ctx);
 /* Number of kernel launches of one mkd_eps at the prepared shape. */
 int     mkd_eps_launches(const mkd_ctx* ctx);
+/* Number of kernel launches of one DDIM step inside mkd_sample at the prepared shape (the time-embedding chain of mkd_eps is
+ * computed once per call there, see mkd_sample; + the step setup and the x_{t-1} update). */
+int     mkd_step_launches(const mkd_ctx* ctx);
 /* Kernel classes of the launch plan, and one mkd_eps with a hipEvent pair around every launch group:
  * per-class device milliseconds, executed FLOPs and launch counts (arrays of mkd_kind_count()). Synchronous.
  * csv_path (host string, may be NULL): also write one line per launch group (op,kind,label,ms,gflop). */

@@ -87,8 +87,25 @@ struct Epi {
 
 typedef std::function<int(hipStream_t)> OpFn;
 
+// What a plan op launches, kept beside its closure for the ops that have a GROUPED form (mkd_common.h: Pair): when the ControlNet
+// and the UNet encoder emit the same op on the same geometry, the pair becomes one launch (mkd_ctx::group_ops).
+enum DescType { D_NONE = 0, D_GEMM, D_GN, D_GN_SLAB, D_LN, D_ATTN, D_CONV_IN };
+struct OpDesc {
+    int type = D_NONE;
+    int sid = 0;                 // workspace set of the op (split-K slabs, GroupNorm partials)
+    GemmArgs gemm;               // D_GEMM; D_GN_SLAB: the split GEMM whose slabs are reduced
+    NormIo nio{};                // D_GN, D_GN_SLAB (x unused), D_LN
+    float eps = 0.f; int silu = 0, ld_in = 0, ld_out = 0, nb = 0, hw = 0, C = 0;      // D_LN: nb = rows, C = d, ld_in = row stride
+    int raw = 0, sk = 0;         // D_GN_SLAB: also store the raw GEMM output; slab count
+    AttnIo aio{}; int ldq = 0, ldk = 0, ldv = 0, ldo = 0, Tq = 0, Tk = 0, heads = 0, dh = 0;      // D_ATTN (nb = samples)
+    ConvInIo cio{}; size_t xoff = 0; int cin = 0, cout = 0, hh = 0, ww = 0;                      // D_CONV_IN (nb = samples)
+    OpDesc() { memset(&gemm, 0, sizeof(gemm)); }
+};
+
 struct Op {
     OpFn fn;
+    OpDesc d;
+    bool temb = false;      // part of the time-embedding chain (left out of the step when mkd_sample runs from its table)
     int kind = 0;
     double flops = 0;
     int launches = 0;
@@ -229,6 +246,7 @@ struct mkd_ctx {
     hipStream_t loop_stream = nullptr; hipEvent_t ev_loop_in = nullptr, ev_loop_out = nullptr;
     hipGraphExec_t multi_graph = nullptr; int multi_graph_steps = 0;      // MKD_GRAPH_STEPS consecutive steps as one graph
     hipGraphExec_t step_graph = nullptr; int step_graph_cfg = -1; float step_graph_scale = 0.f; int plan_generation = 0, step_graph_gen = -1;
+    int step_graph_temb = -1, step_graph_batch = -1;
     // Graph mode 2 (MKD_GRAPH_MODE=2; default 1 = one captured graph per step): one step = LINEAR graphs, one per (stream, stretch
     // between two cross-stream edges), launched on their own streams and ordered by events.  A captured graph with two BRANCHES is
     // replayed with its branches serialised node by node (tools/micro/launch_floor.hip: 3.2 us per pair of empty nodes, 5.3-5.9 us
@@ -240,7 +258,7 @@ struct mkd_ctx {
     struct SegAction { int type; int sid; int idx; };      // type 0: launch seg_graphs[idx] / seg_eager[idx] on stream sid; 1: record event idx on sid; 2: sid waits for event idx
     struct Segment { hipGraphExec_t graph = nullptr; std::vector<OpFn> eager; };
     std::vector<Segment> segs; std::vector<SegAction> seg_actions; std::vector<hipEvent_t> seg_events;
-    int seg_gen = -1, seg_cfg = -1; float seg_scale = 0.f;
+    int seg_gen = -1, seg_cfg = -1, seg_temb = -1, seg_batch = -1; float seg_scale = 0.f;
     int graph_mode = getenv("MKD_GRAPH_MODE") ? atoi(getenv("MKD_GRAPH_MODE")) : 1;
 
     // ---------------------------------------------------------------------------------------------
@@ -596,10 +614,13 @@ struct mkd_ctx {
         if (counting_eps) { launches_eps += launches; flops_eps += flops; }
         if (!dry) {
             Op o; o.fn = std::move(f); o.kind = kind; o.flops = flops; o.launches = launches; o.label = label; o.sid = cur_sid; o.cap_sid = cur_cap_sid;
+            o.temb = cur_temb;
             plan.push_back(std::move(o));
         }
     }
     std::vector<Op>* cur_plan = nullptr;
+    bool cur_temb = false;
+    OpDesc& last_desc() { static OpDesc dummy; return dry ? dummy : cur_plan->back().d; }      // descriptor of the op just pushed
 
     Tensor talloc(Arena& a, int B_, int H_, int W_, int C_) {
         Tensor t; t.B = B_; t.H = H_; t.W = W_; t.C = C_; t.ld = C_;
@@ -607,9 +628,9 @@ struct mkd_ctx {
         return t;
     }
 
-    void op_gemm(GemmArgs a) {
+    void op_gemm(GemmArgs a, int force_splitk = 0) {
         a.zero = zero_page;
-        a.splitk = 0;
+        a.splitk = force_splitk;
         if (gn_colstats_only && a.gn_stat) {
             GnOut g; g.gst = a.gn_stat; g.cg = a.gn_cg; g.coff = a.gn_coff; g.hw = a.gn_hw;
             a.gn_stat = nullptr;
@@ -632,15 +653,16 @@ struct mkd_ctx {
              " res=" + std::to_string(a.R != nullptr) + " f32=" + std::to_string(a.out_f32) + " Hin=" + std::to_string(a.Hin) +
              " Win=" + std::to_string(a.Win) + " Cin=" + std::to_string(a.Cin) + " Hout=" + std::to_string(a.Hout) + " Wout=" + std::to_string(a.Wout) +
              " gn=" + std::to_string(a.gn_stat != nullptr));
+        OpDesc& d = last_desc(); d.type = D_GEMM; d.sid = sid; d.gemm = a;
     }
-    void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false) {
+    void op_linear(const bf16_t* A, int lda, int M, int K, const bf16_t* W, int N, const Epi& e, void* C, int ldc, bool f32out = false, int force_splitk = 0) {
         GemmArgs a; memset(&a, 0, sizeof(a));
         a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = e.bias; a.rowbias = e.rowbias; a.ldrb = e.ldrb;
         a.rows_per_batch = e.rpb; a.R = e.R; a.ldr = e.ldr; a.scale = e.scale; a.act = e.act;
         a.C = C; a.ldc = ldc; a.out_f32 = f32out ? 1 : 0; a.M = M; a.N = N; a.K = K; a.conv = 0;
         a.ln_s = e.ln_s; a.ln_eps = 1e-5f; a.stat_in = e.stat_in; a.stat_in_slots = e.stat_slots; a.stat_out = e.stat_out;
         a.gn_stat = e.gn.gst; a.gn_cg = e.gn.cg; a.gn_coff = e.gn.coff; a.gn_hw = e.gn.hw;
-        op_gemm(a);
+        op_gemm(a, force_splitk);
     }
     // 3x3 conv, pad 1
     void op_conv(const Tensor& in, const bf16_t* W, int N, int stride, int up, const Epi& e, bf16_t* C, int ldc) {
@@ -670,7 +692,7 @@ struct mkd_ctx {
         a.zero = zero_page; a.splitk = 0;
         int cfg_i = 0, sk = 1;
         if (gemm_resolve(a, &cfg_i, &sk) || sk < 2) return false;
-        a.defer_epilogue = 1;
+        a.defer_epilogue = 1; a.expect_splitk = sk;   // (launch_gemm fails if it would resolve to another slab count than the one planned here)
         op_gemm(a);                                   // (counts 2 launches for a split GEMM: corrected below)
         if (counting_eps) --launches_eps;
         if (!dry) cur_plan->back().launches = 1;
@@ -681,6 +703,8 @@ struct mkd_ctx {
             if (!raw) b.C = nullptr;
             return launch_gn_from_slabs(b, gamma, beta, eps, silu, y, ld_y, nb, hw, st);
         }, 1, 0.0, K_GROUPNORM, "slab B=" + std::to_string(nb) + " HW=" + std::to_string(hw) + " C=" + std::to_string(a.N) + " splitk=" + std::to_string(sk));
+        OpDesc& d = last_desc(); d.type = D_GN_SLAB; d.sid = sid; d.gemm = a; d.sk = sk; d.raw = raw ? 1 : 0; d.nio = NormIo{nullptr, y, gamma, beta};
+        d.eps = eps; d.silu = silu; d.ld_out = ld_y; d.nb = nb; d.hw = hw;
         return true;
     }
     void op_gn(const Tensor& in, const float* gamma, const float* beta, float eps, int silu, bf16_t* out, int ld_out) {
@@ -699,10 +723,13 @@ struct mkd_ctx {
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out, sid](hipStream_t st) {
             return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[arena_of(sid)], st);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
+        OpDesc& d = last_desc(); d.type = D_GN; d.sid = sid; d.nio = NormIo{in.p, out, gamma, beta}; d.eps = eps; d.silu = silu;
+        d.ld_in = in.ld; d.ld_out = ld_out; d.nb = in.B; d.hw = in.H * in.W; d.C = in.C;
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d, int ldx = 0) {
         push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st, ldx); }, 1, 0.0, K_LAYERNORM,
              "rows=" + std::to_string(rows) + " d=" + std::to_string(d));
+        OpDesc& ds = last_desc(); ds.type = D_LN; ds.nio = NormIo{x, y, gamma, beta}; ds.eps = 1e-5f; ds.nb = rows; ds.C = d; ds.ld_in = ldx;
     }
     void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
                  int B_, int Tq, int Tk, int heads, int dh) {
@@ -710,6 +737,8 @@ struct mkd_ctx {
         push(*cur_plan, [=](hipStream_t st) { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B_, Tq, Tk, heads, dh, scale, st); },
              1, 4.0 * B_ * heads * (double)Tq * Tk * dh, K_ATTENTION,
              "B=" + std::to_string(B_) + " Tq=" + std::to_string(Tq) + " Tk=" + std::to_string(Tk) + " heads=" + std::to_string(heads) + " dh=" + std::to_string(dh));
+        OpDesc& d = last_desc(); d.type = D_ATTN; d.aio = AttnIo{q, k, v, o}; d.ldq = ldq; d.ldk = ldk; d.ldv = ldv; d.ldo = ldo; d.nb = B_; d.Tq = Tq; d.Tk = Tk;
+        d.heads = heads; d.dh = dh;
     }
     void op_geglu(const bf16_t* x, bf16_t* y, int rows, int inner) {
         push(*cur_plan, [=](hipStream_t st) { return launch_geglu(x, y, rows, inner, st); }, 1, 0.0, K_GEGLU, "rows=" + std::to_string(rows) + " inner=" + std::to_string(inner));
@@ -837,22 +866,101 @@ struct mkd_ctx {
         TA().release(mk);
     }
 
-    // time embedding MLP + every ResBlock's emb projection in one GEMM -> fp32 [B, emb_total]
-    float* time_embedding(int which) {
+    // time embedding MLP + every ResBlock's emb projection in one GEMM -> fp32 [rows, emb_total] at `proj`.  The three GEMMs never
+    // split K (force_splitk = 1): an output element then sees the same sequence of K-steps whatever the tile, so a row of the
+    // per-call table (rows = the sampling call's steps, build_temb_table) is bit-identical to the same timestep evaluated per step.
+    void emit_time_embedding(int which, int rows, const int64_t* const* tsrc, bf16_t* s0, bf16_t* s1, bf16_t* s2, float* proj) {
         const std::string P = net_prefix(which);
         const int mc = cfg.model_channels, te = temb_dim();
-        bf16_t* s0 = (bf16_t*)persist.alloc((size_t)B * mc * sizeof(bf16_t));
-        mkd_ctx* self = this;
-        const int Bn = B;
-        push(*cur_plan, [self, s0, Bn, mc](hipStream_t st) { return launch_timestep_embedding(self->io_t, s0, Bn, mc, st); }, 1, 0.0);
-        bf16_t* s1 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
-        { Epi e; e.bias = wf(P + "time_embed.0.bias"); e.act = 1; op_linear(s0, mc, B, mc, wb(P + "time_embed.0.weight"), te, e, s1, te); }
-        bf16_t* s2 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
+        const bool keep = cur_temb;
+        cur_temb = true;
+        push(*cur_plan, [tsrc, s0, rows, mc](hipStream_t st) { return launch_timestep_embedding(*tsrc, s0, rows, mc, st); }, 1, 0.0);
+        { Epi e; e.bias = wf(P + "time_embed.0.bias"); e.act = 1; op_linear(s0, mc, rows, mc, wb(P + "time_embed.0.weight"), te, e, s1, te, false, 1); }
         // every consumer applies SiLU to emb first (emb_layers = [SiLU, Linear]) -> fold it here
-        { Epi e; e.bias = wf(P + "time_embed.2.bias"); e.act = 1; op_linear(s1, te, B, te, wb(P + "time_embed.2.weight"), te, e, s2, te); }
+        { Epi e; e.bias = wf(P + "time_embed.2.bias"); e.act = 1; op_linear(s1, te, rows, te, wb(P + "time_embed.2.weight"), te, e, s2, te, false, 1); }
+        { Epi e; e.bias = emb_b[which]; op_linear(s2, te, rows, te, emb_w[which], emb_total[which], e, proj, emb_total[which], true, 1); }
+        cur_temb = keep;
+    }
+    // ... of the evaluated batch, from the caller's t (one mkd_eps): buffers in the persistent arena
+    float* time_embedding(int which) {
+        const int mc = cfg.model_channels, te = temb_dim();
+        bf16_t* s0 = (bf16_t*)persist.alloc((size_t)B * mc * sizeof(bf16_t));
+        bf16_t* s1 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
+        bf16_t* s2 = (bf16_t*)persist.alloc((size_t)B * te * sizeof(bf16_t));
         float* proj = (float*)persist.alloc((size_t)B * emb_total[which] * sizeof(float));
-        { Epi e; e.bias = emb_b[which]; op_linear(s2, te, B, te, emb_w[which], emb_total[which], e, proj, emb_total[which], true); }
+        emit_time_embedding(which, B, &io_t, s0, s1, s2, proj);
+        temb_proj[which] = proj;
         return proj;
+    }
+
+    // ---- time embedding of a whole sampling call ---------------------------------------------------------------------------
+    // The timesteps of mkd_sample are a host table (reference diffmk/cddim.py:83-95: ts = full((b,), step)), every sample of a step
+    // shares one, and the embedding chain (sinusoid -> 2 linear layers -> every ResBlock's emb_layers projection: 75 MB of weights
+    // for 8 rows) depends on nothing else.  So one pass computes [n_steps, emb_total] per net before the loop, and a step only copies
+    // its row into the [B, emb_total] buffers the ResBlock epilogues read (step_setup_kernel / temb_select_kernel): 8-10 dependent
+    // launches leave every step.  MKD_TEMB_TABLE=0: per-step chain as in mkd_eps.
+    bool temb_table = getenv("MKD_TEMB_TABLE") ? atoi(getenv("MKD_TEMB_TABLE")) != 0 : true;
+    bool temb_skip = false;                       // set while a sampling loop runs from the table: the plan's own chain is left out
+    float* temb_proj[2] = {nullptr, nullptr};     // [B, emb_total] per net (persistent arena)
+    float* temb_tab[2] = {nullptr, nullptr};      // [steps, emb_total] per net
+    int64_t* temb_t = nullptr;                    // device copy of the call's timesteps
+    int temb_steps = 0, temb_gen = -1, temb_cap = 0;
+    bf16_t* temb_s[2][3] = {};                    // sinusoid and the two hidden layers of the table pass, [temb_cap, .]
+    std::vector<void*> temb_owned;
+    std::vector<Op> plan_temb_tab;
+    void drop_temb_table() {
+        for (void* q : temb_owned) hipFree(q);
+        temb_owned.clear(); plan_temb_tab.clear();
+        temb_tab[0] = temb_tab[1] = nullptr; temb_t = nullptr; temb_steps = 0; temb_gen = -1; temb_cap = 0;
+    }
+    // buffers grow only (captured step graphs hold the table pointers: they are dropped when the table moves); the launch list is
+    // re-emitted whenever the step count or the plan changes
+    int build_temb_table(int n_steps) {
+        if (temb_gen == plan_generation && temb_steps == n_steps) return 0;
+        const int nets = has_control ? 2 : 1;
+        const bool realloc = n_steps > temb_cap || !temb_t || !temb_tab[0] || (nets == 2 && !temb_tab[1]);
+        const int mc = cfg.model_channels, te = temb_dim();
+        if (realloc) {
+            MKD_HIP_CHECK(hipDeviceSynchronize());      // (a previous loop may still read the old table)
+            drop_temb_table();
+            drop_graph();
+            auto dalloc = [&](size_t bytes, void** out) -> int {
+                MKD_HIP_CHECK(hipMalloc(out, bytes));
+                temb_owned.push_back(*out);
+                return 0;
+            };
+            const int cap = std::max(64, n_steps);
+            int rc = dalloc((size_t)cap * sizeof(int64_t), (void**)&temb_t);
+            for (int which = 0; which < nets && !rc; ++which) {
+                rc = dalloc((size_t)cap * mc * sizeof(bf16_t), (void**)&temb_s[which][0]);
+                if (!rc) rc = dalloc((size_t)cap * te * sizeof(bf16_t), (void**)&temb_s[which][1]);
+                if (!rc) rc = dalloc((size_t)cap * te * sizeof(bf16_t), (void**)&temb_s[which][2]);
+                if (!rc) rc = dalloc((size_t)cap * emb_total[which] * sizeof(float), (void**)&temb_tab[which]);
+            }
+            if (rc) { drop_temb_table(); return rc; }
+            temb_cap = cap;
+        }
+        plan_temb_tab.clear();
+        std::vector<Op>* keep_plan = cur_plan; const int keep_sid = cur_sid; const bool keep_count = counting_eps;
+        cur_plan = &plan_temb_tab; cur_sid = 0; counting_eps = false;
+        for (int which = 0; which < nets; ++which)
+            emit_time_embedding(which, n_steps, &temb_t, temb_s[which][0], temb_s[which][1], temb_s[which][2], temb_tab[which]);
+        cur_plan = keep_plan; cur_sid = keep_sid; counting_eps = keep_count;
+        temb_steps = n_steps; temb_gen = plan_generation;
+        return 0;
+    }
+    TembSel temb_sel() const {
+        TembSel ts;
+        for (int k = 0; k < 2; ++k) { ts.tab[k] = temb_tab[k]; ts.proj[k] = temb_proj[k]; ts.n[k] = (temb_tab[k] && temb_proj[k]) ? emb_total[k] : 0; }
+        ts.batch = B;
+        return ts;
+    }
+    // fills the table for this call's timesteps (host array) on `stream`
+    int run_temb_table(int n_steps, const int64_t* timesteps, hipStream_t stream) {
+        int rc = build_temb_table(n_steps); if (rc) return rc;
+        MKD_HIP_CHECK(hipMemcpyAsync(temb_t, timesteps, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        for (auto& op : plan_temb_tab) { rc = op.fn(stream); if (rc) return rc; }
+        return 0;
     }
 
     static Tensor slice(Tensor t, int b0, int nb) {
@@ -907,6 +1015,7 @@ struct mkd_ctx {
                 push(*cur_plan, [self, wgt, bias, o, add, nb, hh, ww, cin, cout, xoff](hipStream_t st) {
                     return launch_conv3x3_direct(self->io_x + xoff, 1, wgt, bias, o.p, 0, 0, add, nb, hh, ww, cin, cout, 1, st);
                 }, 1, 2.0 * nb * h * w * b.cout * 9 * b.cin, K_CONV_DIRECT);
+                { OpDesc& d = last_desc(); d.type = D_CONV_IN; d.cio = ConvInIo{wgt, bias, o.p, add}; d.xoff = xoff; d.nb = nb; d.hh = hh; d.ww = ww; d.cin = cin; d.cout = cout; }
                 op_colstats(o.p, o.ld, o.B, o.H * o.W, o.C, gn_of(o));
             } else if (b.kind == 1) {
                 if (b.attn) {
@@ -1014,8 +1123,13 @@ struct mkd_ctx {
         // nets run on different streams, each optionally as two half-batch lanes (UNet lanes on streams 0 / 2, ControlNet lanes
         // on 1 / 3), with the host enqueue order interleaved so all streams are fed from the first launch on.  These kernels are
         // latency-bound (a batch-2 evaluation takes 60 % of a batch-8 one), so concurrency is what pays.
-        const int EL = (enc_lanes && B >= 2) ? 2 : 1;
+        // enc_group (MKD_ENC_GROUP=1): the two nets become ONE chain of grouped launches instead (group_ops): built to test whether the
+        // dispatcher cost of two dependent chains (tools/micro/launch_floor.hip) outweighs what their overlap hides - it does not, see
+        // the measurement at enc_group.
+        const bool grouped = enc_group && has_control;
+        const int EL = (!grouped && enc_lanes && B >= 2) ? 2 : 1;
         float* ep0 = nullptr; float* ep1 = nullptr;
+        temb_proj[0] = temb_proj[1] = nullptr;
         cur_plan = &plan_eps;
         cur_sid = 0;
         if (gn_fused)           // the GroupNorm statistics of this evaluation start from zero (one memset node for all of them)
@@ -1023,13 +1137,17 @@ struct mkd_ctx {
                 // a kernel, not hipMemsetAsync: as a memset NODE of the captured step graph it costs 1.6 ms per replay (measured)
                 return self->gstat.high ? launch_fill_i64((int64_t*)self->gstat_base, 0, (int)(self->gstat.high / 8), st) : 0;
             }, 1, 0.0, K_MISC, "gn_stat_zero");
-        if (has_control) op_edge(0, 1, true, true);      // side stream starts after everything already enqueued by the caller
-        cur_sid = 0; ep0 = time_embedding(0);
-        if (has_control) { cur_sid = 1; ep1 = time_embedding(1); }
-        if (EL == 2) { op_edge(0, 2, true, true); if (has_control) op_edge(1, 3, true, true); }
+        if (has_control && !grouped) op_edge(0, 1, true, true);      // side stream starts after everything already enqueued by the caller
+        std::vector<Op> lists[NS];
+        cur_plan = &lists[0]; cur_sid = 0; ep0 = time_embedding(0);
+        if (has_control) { cur_plan = &lists[1]; cur_sid = 1; ep1 = time_embedding(1); }
+        cur_plan = &plan_eps; cur_sid = 0;
+        if (EL == 2) {          // (the lanes fork after the time embedding of their net)
+            for (int k = 0; k < 2; ++k) { for (auto& o : lists[k]) plan_eps.push_back(std::move(o)); lists[k].clear(); }
+            op_edge(0, 2, true, true); if (has_control) op_edge(1, 3, true, true);
+        }
         alloc_encoder(hs, u_mid);
         if (has_control) alloc_encoder(cn_feats, cn_mid);
-        std::vector<Op> lists[NS];
         for (int l = 0; l < EL; ++l) {
             const int nb0 = EL == 2 ? B / 2 : B;
             const int b0 = l ? nb0 : 0, nb = l ? B - nb0 : nb0;
@@ -1037,16 +1155,17 @@ struct mkd_ctx {
             cur_plan = &lists[2 * l]; cur_sid = 2 * l; encoder_lane(0, ep0, hs, u_mid, b0, nb);
         }
         cur_plan = &plan_eps; cur_sid = 0;
-        {
+        if (grouped) group_ops(lists[0], lists[1], plan_eps);
+        else {
             size_t idx[NS] = {};
             for (bool more = true; more;) {
                 more = false;
                 for (int k : {1, 0, 3, 2})
                     if (idx[k] < lists[k].size()) { plan_eps.push_back(std::move(lists[k][idx[k]++])); more = true; }
             }
+            for (int k = 1; k < NS; ++k)
+                if (!lists[k].empty()) op_edge(k, 0, true, true);      // join: the decoder needs every encoder lane
         }
-        for (int k = 1; k < NS; ++k)
-            if (!lists[k].empty()) op_edge(k, 0, true, true);      // join: the decoder needs every encoder lane
 
         auto dec = decoder_spec();
         const std::string P = net_prefix(0), PC = net_prefix(1);
@@ -1193,6 +1312,110 @@ struct mkd_ctx {
             emit_decoder(0, B, dec_overlap, 0, dec.size(), false);
         }
         counting_eps = false;
+        if (!dry) {          // (grouping changed the launch count: take it from the plan itself)
+            launches_eps = 0; launches_temb = 0; flops_eps = 0;
+            for (auto& op : plan_eps) { launches_eps += op.launches; flops_eps += op.flops; if (op.temb) launches_temb += op.launches; }
+        }
+    }
+
+    // ---- grouped launches of the encoder phase ----------------------------------------------------------------------------------
+    // MKD_ENC_GROUP=1: ControlNet and UNet encoder + middle block as one chain of 2-problem launches on the caller's stream; 0 (the
+    // default): two chains on two streams.  Measured at batch 8, 256x256, graph replay, latents only (tools/exp_r3_group.sh, two
+    // alternating rounds on one box): two chains 5.64 ms per evaluation (728 launches), grouped 6.19-6.25 ms (576-582 launches) -
+    // 146 launches fewer and 10 % SLOWER.  A grouped kernel takes twice the time of one of its halves (the serial sum of kernel
+    // times barely moves: 10.35 -> 9.4 ms with ~4 us of event overhead per launch in both), so what grouping removes is one
+    // fixed cost per pair - and that is exactly what the second chain already hides: while one chain's kernel drains, dispatches and
+    // fills its first tiles, the other chain's kernel has the CUs (pair = max(L + W, 2 W) on two chains, L + 2 W grouped).
+    bool enc_group = getenv("MKD_ENC_GROUP") ? atoi(getenv("MKD_ENC_GROUP")) != 0 : false;
+    int launches_temb = 0;
+    // u / c: the op lists of the UNet and the ControlNet encoder (same architecture, emitted by the same code).  Ops whose
+    // descriptors agree in kind and geometry become ONE launch over both problems; anything else runs one after the other.  Either
+    // way everything lands on stream 0: the ControlNet keeps its own temporaries and workspaces (arena 1), only its stream goes.
+    void group_ops(std::vector<Op>& u, std::vector<Op>& c, std::vector<Op>& out) {
+        auto single = [&](Op& o) { o.sid = 0; o.cap_sid = -1; out.push_back(std::move(o)); };
+        if (u.size() != c.size()) {          // (not the same op sequence after all: no pairing)
+            for (auto& o : u) single(o);
+            for (auto& o : c) single(o);
+            return;
+        }
+        for (size_t i = 0; i < u.size(); ++i) {
+            Op g;
+            if (make_group(u[i], c[i], &g)) out.push_back(std::move(g));
+            else { single(u[i]); single(c[i]); }
+        }
+    }
+    bool make_group(const Op& a, const Op& b, Op* out) {
+        const OpDesc& x = a.d; const OpDesc& y = b.d;
+        if (x.type == D_NONE || x.type != y.type || a.kind != b.kind || a.launches != b.launches || a.temb != b.temb) return false;
+        if (arena_of(x.sid) == arena_of(y.sid) && (x.type == D_GEMM || x.type == D_GN_SLAB)) return false;      // (split-K slabs per problem)
+        mkd_ctx* self = this;
+        OpFn fn;
+        switch (x.type) {
+            case D_GEMM: {
+                if (!gemm_same_geometry(x.gemm, y.gemm)) return false;
+                const GemmArgs ga = x.gemm, gb = y.gemm; const int sa = x.sid, sb = y.sid;
+                fn = [self, ga, gb, sa, sb](hipStream_t st) {
+                    GemmArgs p = ga, q = gb;
+                    p.ws = self->splitk_ws[arena_of(sa)]; p.ws_bytes = self->splitk_ws_bytes[arena_of(sa)];
+                    q.ws = self->splitk_ws[arena_of(sb)]; q.ws_bytes = self->splitk_ws_bytes[arena_of(sb)];
+                    return launch_gemm(p, st, &q);
+                };
+                break;
+            }
+            case D_GN_SLAB: {
+                if (!gemm_same_geometry(x.gemm, y.gemm) || x.sk != y.sk || x.raw != y.raw || x.eps != y.eps || x.silu != y.silu || x.ld_out != y.ld_out ||
+                    x.nb != y.nb || x.hw != y.hw) return false;
+                const OpDesc dx = x, dy = y;
+                fn = [self, dx, dy](hipStream_t st) {
+                    GemmArgs p = dx.gemm, q = dy.gemm;
+                    p.ws = self->splitk_ws[arena_of(dx.sid)]; p.splitk = dx.sk; q.ws = self->splitk_ws[arena_of(dy.sid)]; q.splitk = dy.sk;
+                    if (!dx.raw) { p.C = nullptr; q.C = nullptr; }
+                    return launch_gn_from_slabs(p, dx.nio.gamma, dx.nio.beta, dx.eps, dx.silu, dx.nio.y, dx.ld_out, dx.nb, dx.hw, st, &q, &dy.nio);
+                };
+                break;
+            }
+            case D_GN: {
+                if (x.eps != y.eps || x.silu != y.silu || x.ld_in != y.ld_in || x.ld_out != y.ld_out || x.nb != y.nb || x.hw != y.hw || x.C != y.C) return false;
+                const OpDesc dx = x, dy = y;
+                fn = [self, dx, dy](hipStream_t st) {
+                    return launch_groupnorm(dx.nio.x, dx.ld_in, dx.nio.gamma, dx.nio.beta, dx.eps, dx.silu, dx.nio.y, dx.ld_out, dx.nb, dx.hw, dx.C, 32,
+                                            self->gn_ws[arena_of(dx.sid)], st, &dy.nio);
+                };
+                break;
+            }
+            case D_LN: {
+                if (x.eps != y.eps || x.nb != y.nb || x.C != y.C || x.ld_in != y.ld_in) return false;
+                const OpDesc dx = x, dy = y;
+                fn = [dx, dy](hipStream_t st) { return launch_layernorm(dx.nio.x, dx.nio.gamma, dx.nio.beta, dx.eps, dx.nio.y, dx.nb, dx.C, st, dx.ld_in, &dy.nio); };
+                break;
+            }
+            case D_ATTN: {
+                if (x.ldq != y.ldq || x.ldk != y.ldk || x.ldv != y.ldv || x.ldo != y.ldo || x.nb != y.nb || x.Tq != y.Tq || x.Tk != y.Tk || x.heads != y.heads ||
+                    x.dh != y.dh) return false;
+                const OpDesc dx = x, dy = y;
+                fn = [dx, dy](hipStream_t st) {
+                    return launch_attention(dx.aio.q, dx.ldq, dx.aio.k, dx.ldk, dx.aio.v, dx.ldv, dx.aio.o, dx.ldo, dx.nb, dx.Tq, dx.Tk, dx.heads, dx.dh,
+                                            1.0f / sqrtf((float)dx.dh), st, 0, &dy.aio);
+                };
+                break;
+            }
+            case D_CONV_IN: {
+                if (x.xoff != y.xoff || x.nb != y.nb || x.hh != y.hh || x.ww != y.ww || x.cin != y.cin || x.cout != y.cout || x.cin != 4 || x.cout < 64 || x.cout > 512)
+                    return false;
+                const OpDesc dx = x, dy = y;
+                fn = [self, dx, dy](hipStream_t st) {
+                    return launch_conv3x3_direct(self->io_x + dx.xoff, 1, dx.cio.w, dx.cio.bias, dx.cio.y, 0, 0, dx.cio.add, dx.nb, dx.hh, dx.ww, dx.cin, dx.cout, 1, st,
+                                                 &dy.cio);
+                };
+                break;
+            }
+            default: return false;
+        }
+        Op g;
+        g.fn = std::move(fn); g.kind = a.kind; g.flops = a.flops + b.flops; g.launches = a.launches; g.label = a.label + " x2"; g.sid = 0; g.cap_sid = -1;
+        g.temb = a.temb;
+        *out = std::move(g);
+        return true;
     }
 
     int ensure(void** p, size_t* have, size_t need) {
@@ -1270,6 +1493,7 @@ struct mkd_ctx {
         io_x = x; io_t = t; io_out = out;
         run_main = stream; run_serial = !dual_stream;
         for (auto& op : plan_eps) {
+            if (op.temb && temb_skip) continue;          // (mkd_sample filled the rows from its per-call table)
             const int sid = (capturing && op.cap_sid >= 0) ? op.cap_sid : op.sid;
 #ifdef MKD_EXP_ABLATE
             // experiment build only (tools/exp_ablate.sh): leave a whole kernel class out of the evaluation (WRONG results) to bound what
@@ -1364,7 +1588,9 @@ struct mkd_ctx {
         struct Item { OpFn fn; int sid; int from, to; };
         std::vector<Item> items;
         const int Bn = B;
-        items.push_back({[self, Bn](hipStream_t st) { return launch_step_setup(self->s_state, self->s_t, Bn, st); }, 0, -1, -1});
+        items.push_back({[self, Bn](hipStream_t st) {
+            const TembSel ts = self->temb_sel();
+            return launch_step_setup(self->s_state, self->s_t, Bn, st, self->temb_skip ? &ts : nullptr); }, 0, -1, -1});
         const float* ec; const float* eu = nullptr;
         if (cfg_on) {
             items.push_back({[self, n](hipStream_t st) { return launch_repeat_batch(self->s_xa, self->s_xin, n, 2, st); }, 0, -1, -1});
@@ -1374,6 +1600,7 @@ struct mkd_ctx {
         for (auto& op : plan_eps) {
             if (op.edge_from >= 0) { if (op.edge_in_graph) items.push_back({nullptr, 0, arena_of(op.edge_from), arena_of(op.edge_to)}); continue; }
             if (op.launches == 0 && op.kind == K_MISC && op.label.rfind("edge", 0) == 0) continue;
+            if (op.temb && temb_skip) continue;
 #ifdef MKD_EXP_ABLATE
             {   // experiment build only: the same class switches as in eps()
                 static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;
@@ -1437,7 +1664,7 @@ struct mkd_ctx {
         for (int sid = NS - 1; sid >= 0 && !rc; --sid) rc = flush(sid);      // (every side stream was joined by an edge: only stream 0 has work left)
         capturing = false;
         if (rc) { drop_segments(); return rc; }
-        seg_gen = plan_generation; seg_cfg = (int)cfg_on; seg_scale = cfg_scale;
+        seg_gen = plan_generation; seg_cfg = (int)cfg_on; seg_scale = cfg_scale; seg_temb = (int)temb_skip; seg_batch = batch;
         return 0;
     }
     int run_segments() {
@@ -1463,7 +1690,8 @@ struct mkd_ctx {
     // enqueue ONE reverse step that reads its timestep / coefficients from the device step state (graph body)
     int enqueue_state_step(int batch, bool cfg_on, float cfg_scale, hipStream_t stream) {
         const int64_t n = (int64_t)batch * cfg.in_channels * h * w;
-        int rc = launch_step_setup(s_state, s_t, B, stream); if (rc) return rc;
+        const TembSel ts = temb_sel();
+        int rc = launch_step_setup(s_state, s_t, B, stream, temb_skip ? &ts : nullptr); if (rc) return rc;
         const float* ec; const float* eu = nullptr;
         if (cfg_on) {
             rc = launch_repeat_batch(s_xa, s_xin, n, 2, stream); if (rc) return rc;
@@ -1477,6 +1705,12 @@ struct mkd_ctx {
     }
 
     int sample(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
+               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
+        const int rc = sample_impl(x_T, batch, n_steps, timesteps, alphas, alphas_prev, s1m, cfg_scale, x_out, use_graph, stream);
+        temb_skip = false;          // (a later mkd_eps runs its own time-embedding chain)
+        return rc;
+    }
+    int sample_impl(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
                const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_sample before mkd_prepare");
         const bool cfg_on = cfg_scale != 1.0f;
@@ -1510,9 +1744,13 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipEventRecord(ev_loop_in, stream));
             MKD_HIP_CHECK(hipStreamWaitEvent(loop_stream, ev_loop_in, 0));
             MKD_HIP_CHECK(hipMemcpyAsync(s_state, h_state, sizeof(StepState), hipMemcpyHostToDevice, loop_stream));
+            if (temb_table) {
+                int rc = run_temb_table(n_steps, timesteps, loop_stream); if (rc) return rc;
+                temb_skip = true;
+            }
             if (graph_mode == 2 && dual_stream) {
                 run_main = loop_stream; run_serial = false;
-                if (segs.empty() || seg_gen != plan_generation || seg_cfg != (int)cfg_on || seg_scale != cfg_scale) {
+                if (segs.empty() || seg_gen != plan_generation || seg_cfg != (int)cfg_on || seg_scale != cfg_scale || seg_temb != (int)temb_skip || seg_batch != batch) {
                     int rc = build_segments(batch, cfg_on, cfg_scale); if (rc) return rc;
                 }
                 for (int i = 0; i < n_steps; ++i) { int rc = run_segments(); if (rc) return rc; }
@@ -1521,7 +1759,9 @@ struct mkd_ctx {
                 MKD_HIP_CHECK(hipStreamWaitEvent(stream, ev_loop_out, 0));
                 return 0;
             }
-            if (!step_graph || step_graph_gen != plan_generation || step_graph_cfg != (int)cfg_on || step_graph_scale != cfg_scale) {
+            // both graphs are keyed on everything their nodes depend on (plan, guidance, batch, where the time embedding comes from)
+            if (!step_graph || step_graph_gen != plan_generation || step_graph_cfg != (int)cfg_on || step_graph_scale != cfg_scale ||
+                step_graph_temb != (int)temb_skip || step_graph_batch != batch) {
                 drop_graph();
                 hipGraph_t g = nullptr;
                 MKD_HIP_CHECK(hipStreamBeginCapture(loop_stream, hipStreamCaptureModeRelaxed));
@@ -1535,6 +1775,7 @@ struct mkd_ctx {
                 hipGraphDestroy(g);
                 if (e != hipSuccess) { step_graph = nullptr; return mkd_fail(MKD_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
                 step_graph_gen = plan_generation; step_graph_cfg = (int)cfg_on; step_graph_scale = cfg_scale;
+                step_graph_temb = (int)temb_skip; step_graph_batch = batch;
             }
             // MKD_GRAPH_STEPS = k > 1: k consecutive steps captured as ONE graph (the step reads its index from the device-resident
             // counter, so the same capture repeated k times is k different steps); the remainder runs on the single-step graph
@@ -1566,10 +1807,15 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipStreamWaitEvent(stream, ev_loop_out, 0));
             return 0;
         }
+        if (temb_table) {
+            int rc = run_temb_table(n_steps, timesteps, stream); if (rc) return rc;
+            temb_skip = true;
+        }
         float* xa = s_xa; float* xb = s_xb;
         for (int i = 0; i < n_steps; ++i) {
             const int index = n_steps - 1 - i;
             int rc = launch_fill_i64(s_t, timesteps[index], B, stream); if (rc) return rc;
+            if (temb_skip) { rc = launch_temb_select(temb_sel(), index, stream); if (rc) return rc; }
             const float* ec; const float* eu = nullptr;
             if (cfg_on) {
                 rc = launch_repeat_batch(xa, s_xin, n, 2, stream); if (rc) return rc;
@@ -1966,6 +2212,7 @@ struct mkd_ctx {
         if (carena_base) hipFree(carena_base);
         for (auto& kv : f32_keep) hipFree(kv.second);
         drop_graph();
+        drop_temb_table();
         for (hipEvent_t e : aux_ev) hipEventDestroy(e);
         for (hipEvent_t e : seg_events) hipEventDestroy(e);
         if (loop_stream) { hipStreamSynchronize(loop_stream); hipStreamDestroy(loop_stream); hipEventDestroy(ev_loop_in); hipEventDestroy(ev_loop_out); }
@@ -2122,6 +2369,10 @@ int mkd_clip_encode(mkd_ctx* ctx, const int32_t* tokens, int batch, int n_tokens
 }
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }
+int mkd_step_launches(const mkd_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->launches_eps - (ctx->temb_table ? ctx->launches_temb : 0) + 2;      // + step setup + DDIM update
+}
 int64_t mkd_device_bytes(const mkd_ctx* ctx) { return ctx ? ctx->device_bytes() : 0; }
 
 // ---- single-kernel entry points ----------------------------------------------------------------------

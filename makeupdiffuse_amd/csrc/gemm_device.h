@@ -7,10 +7,12 @@ namespace mkdk {
 // XCD-aware tile order.  The dispatcher deals workgroups to the 8 XCDs round-robin in launch order (x fastest), so workgroup `lid`
 // runs on XCD lid % 8 as the (lid / 8)-th workgroup there.  Give every XCD one CONTIGUOUS run of the tile sequence instead: tiles that
 // share an operand tile then sit in the same L2 at the same time.  Uniform (scalar) arithmetic only.
-__device__ __forceinline__ void xcd_tile_order(int mode, int& bx, int& by, int& bz) {
-    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+// gz / grp: a grouped launch stacks the second problem's grid above the first one's in z (gz = z extent of one problem); every
+// problem is ordered on its own.
+__device__ __forceinline__ void xcd_tile_order(int mode, int gz, int grp, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = (int)blockIdx.z - grp * gz;
     if (mode == 0) return;
-    const int gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * (int)gridDim.z;
+    const int gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * gz;
     const int lid = bx + gx * by + plane * bz;
     const int xcd = lid & 7, idx = lid >> 3, q = total >> 3, r = total & 7;
     const int t = xcd * q + (xcd < r ? xcd : r) + idx;       // XCD k owns tiles [k*q + min(k, r), ...): q (+1 for k < r) of them
@@ -20,7 +22,13 @@ __device__ __forceinline__ void xcd_tile_order(int mode, int& bx, int& by, int& 
     else { bx = rem / gy; by = rem - bx * gy; }              // y fastest: consecutive tiles share the A tile
 }
 
-
+// host side: the 2-entry argument table of a (possibly grouped) launch; gz = z extent of one problem's grid
+inline GemmArgs2 gemm_pack2(const GemmArgs& a, const GemmArgs* b, int gz) {
+    GemmArgs2 r;
+    r.g[0] = a; r.g[0].gz = gz;
+    r.g[1] = b ? *b : a; r.g[1].gz = gz;
+    return r;
+}
 
 constexpr int BK = 64;
 

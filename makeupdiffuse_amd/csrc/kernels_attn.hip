@@ -47,11 +47,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
 template <int DH, int NW, int KT>
-__global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
-                                                        const bf16_t* __restrict__ K, int ldk,
-                                                        const bf16_t* __restrict__ V, int ldv,
-                                                        bf16_t* __restrict__ O, int ldo,
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> io, int ldq, int ldk, int ldv, int ldo,
                                                         int Tq, int Tk, int heads, float scale_log2e, int causal) {
+    // grouped launch: grid z selects the problem (same geometry, own tensors)
+    const bf16_t* __restrict__ const Q = io.g[blockIdx.z].q; const bf16_t* __restrict__ const K = io.g[blockIdx.z].k;
+    const bf16_t* __restrict__ const V = io.g[blockIdx.z].v; bf16_t* __restrict__ const O = io.g[blockIdx.z].o;
     using C = AttnCfg<DH, KT>;
     static_assert(KT % 32 == 0, "key tile: whole 32-key PV steps");
     constexpr int KB = KT / 16;          // 16-key blocks of S^T
@@ -254,15 +254,18 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
-                     hipStream_t stream, int causal) {
+                     hipStream_t stream, int causal, const AttnIo* second) {
     if (Tq <= 0 || Tk <= 0 || batch <= 0 || heads <= 0) return mkd_fail(-1, "attention: empty problem");
+    Pair<AttnIo> io;
+    io.g[0] = AttnIo{q, k, v, o};
+    io.g[1] = second ? *second : io.g[0];
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
     const float sl = scale * 1.4426950408889634f;
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
     static const bool kt96 = !(getenv("MKD_ATTN_KT96") && atoi(getenv("MKD_ATTN_KT96")) == 0);      // (A/B knob)
     const bool one96 = kt96 && !wide && !causal && Tk > 64 && Tk <= 96;      // cross-attention (77 context keys): one 96-key tile
     const int qb = wide ? 128 : 64;
-    dim3 grid((Tq + qb - 1) / qb, batch * heads);
+    dim3 grid((Tq + qb - 1) / qb, batch * heads, second ? 2 : 1);
 #define MKD_ATTN_LAUNCH(D, NWV, KTV)                                                                          \
     do {                                                                                                      \
         constexpr int lds = AttnCfg<D, KTV>::KBYTES + AttnCfg<D, KTV>::VBYTES;                                  \
@@ -272,7 +275,7 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(attention LDS): ") + hipGetErrorString(e));            \
             attr = true;                                                                                      \
         }                                                                                                     \
-        hipLaunchKernelGGL((attention_kernel<D, NWV, KTV>), grid, dim3(64 * NWV), lds, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,     \
+        hipLaunchKernelGGL((attention_kernel<D, NWV, KTV>), grid, dim3(64 * NWV), lds, stream, io, ldq, ldk, ldv, ldo, Tq, Tk,     \
                            heads, sl, causal);                                                                \
     } while (0)
 #define MKD_ATTN_CASE(D)                                                                                      \

@@ -26,8 +26,10 @@ using namespace mkdk;
 // GNS = 1: the epilogue also accumulates the GroupNorm statistics of the output (gemm_device.h); separate instantiation so that
 // the plain kernel keeps its registers and occupancy
 template <int TM, int TN, int WM, int WN, int STAGES, int PP, int GNS = 0>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmArgs2 pg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = (int)blockIdx.z >= pg.g[0].gz ? 1 : 0;      // grouped launch: the second problem owns the upper half of grid z
+    const GemmArgs& p = pg.g[grp];
     constexpr int NW = WM * WN;
     constexpr int WP = TN / 8 / NW;          // W pieces (1 KiB = 8 rows x 128 B) per wave per tile
     constexpr int NI = TN / WN / 16;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     const int PH = TH + 2, PW = TW + 2, PPIX = PH * PW, NP = IMGS * PPIX;
     const int tiles_x = Wd / TW, tiles_y = H / TH;
     int bid, by, bz;
-    xcd_tile_order(p.xcd_mode, bid, by, bz);
+    xcd_tile_order(p.xcd_mode, p.gz, grp, bid, by, bz);
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
     const int b0 = (bid / (tiles_x * tiles_y)) * IMGS;
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
 }
 
 template <int TM, int TN, int WM, int WN, int PP>
-int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, (int)grid.z);
+    if (second) grid.z *= 2;
     constexpr int STAGES = 3;
     constexpr int NW = WM * WN;
     const bool gns = a.gn_stat != nullptr && a.splitk == 1;
@@ -333,27 +337,27 @@ int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(conv patch LDS): ") + hipGetErrorString(e));
         attr_set[gns] = true;
     }
-    if (gns) hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 1>), grid, dim3(64 * NW), lds, stream, a);
-    else     hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 0>), grid, dim3(64 * NW), lds, stream, a);
+    if (gns) hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 1>), grid, dim3(64 * NW), lds, stream, ag);
+    else     hipLaunchKernelGGL((conv3x3_patch_kernel<TM, TN, WM, WN, STAGES, PP, 0>), grid, dim3(64 * NW), lds, stream, ag);
     return 0;
 }
 
 template <int TM, int TN, int WM, int WN>
-int launch_patch_pp(const GemmArgs& a, int pp, dim3 grid, hipStream_t stream) {
+int launch_patch_pp(const GemmArgs& a, int pp, dim3 grid, hipStream_t stream, const GemmArgs* second) {
     if constexpr (WM * WN == 16) {                      // 16 waves: 2 or 3 pieces per wave hold a 256- / 128-pixel patch
-        if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream);
-        if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream);
+        if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream, second);
+        if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream, second);
         return mkd_fail(-4, "conv3x3_patch: patch too large for the 16-wave tile");
     } else {
         if constexpr (WM * WN == 8 && TM <= 128) {      // 8 waves on a 64- / 128-pixel tile: 2 or 3 pieces per wave hold the patch
-            if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream);
-            if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream);
+            if (pp <= 2) return launch_patch<TM, TN, WM, WN, 2>(a, grid, stream, second);
+            if (pp == 3) return launch_patch<TM, TN, WM, WN, 3>(a, grid, stream, second);
         }
-        if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream);
-        if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream);
-        if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream);
-        if (pp == 7) return launch_patch<TM, TN, WM, WN, 7>(a, grid, stream);
-        if (pp <= 9) return launch_patch<TM, TN, WM, WN, 9>(a, grid, stream);
+        if (pp <= 4) return launch_patch<TM, TN, WM, WN, 4>(a, grid, stream, second);
+        if (pp == 5) return launch_patch<TM, TN, WM, WN, 5>(a, grid, stream, second);
+        if (pp == 6) return launch_patch<TM, TN, WM, WN, 6>(a, grid, stream, second);
+        if (pp == 7) return launch_patch<TM, TN, WM, WN, 7>(a, grid, stream, second);
+        if (pp <= 9) return launch_patch<TM, TN, WM, WN, 9>(a, grid, stream, second);
         return mkd_fail(-4, "conv3x3_patch: patch too large");
     }
 }
@@ -408,8 +412,9 @@ bool conv_patch_supported(const GemmArgs& a, int cfg) {
     return lds <= 160 * 1024;
 }
 
-int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
+int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream, const GemmArgs* second) {
     if (!conv_patch_supported(a, cfg)) return mkd_fail(-4, "conv3x3_patch: unsupported shape for this tile");
+    if (second && !gemm_same_geometry(a, *second)) return mkd_fail(-1, "conv3x3_patch: a grouped launch needs two problems of identical geometry");
     int tm, tn, nw;
     patch_cfg_shape(cfg, &tm, &tn, &nw);
     const int batch = a.M / (a.Hin * a.Win);
@@ -420,28 +425,39 @@ int launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream) {
     if (s > nch) s = nch;
     const int per = (nch + s - 1) / s;
     s = (nch + per - 1) / per;
+    if (a.defer_epilogue && (s < 2 || (a.expect_splitk > 0 && s != a.expect_splitk)))
+        return mkd_fail(-3, "conv3x3_patch: deferred split-K epilogue planned for " + std::to_string(a.expect_splitk) + " slabs, the launch resolves to " +
+                                std::to_string(s) + " (tile / split-K settings changed after mkd_prepare: prepare again)");
     if (s > 1 && !a.ws) return mkd_fail(-1, "conv3x3_patch: split-K needs a workspace");
     if (s > 1 && gemm_ws_bytes(a.M, a.N, s) > a.ws_bytes) return mkd_fail(-1, "conv3x3_patch: split-K workspace too small");
+    if (s > 1 && second && (!second->ws || second->ws == a.ws || gemm_ws_bytes(a.M, a.N, s) > second->ws_bytes))
+        return mkd_fail(-1, "conv3x3_patch: split-K needs a workspace per problem");
     a.splitk = s;
     a.ksteps_per_split = per;
+    GemmArgs b;
+    if (second) {
+        b = *second; b.zero = a.zero; b.splitk = s; b.ksteps_per_split = per; b.xcd_mode = a.xcd_mode;
+        b.tile_h = a.tile_h; b.tile_w = a.tile_w; b.tile_imgs = a.tile_imgs;
+    }
+    const GemmArgs* const sp = second ? &b : nullptr;
     const int groups = (batch + a.tile_imgs - 1) / a.tile_imgs;
     dim3 grid(groups * (a.Hin / a.tile_h) * (a.Win / a.tile_w), (a.N + tn - 1) / tn, s);
     int rc;
     switch (cfg) {
-        case 6: rc = launch_patch_pp<256, 128, 4, 2>(a, pp, grid, stream); break;
-        case 7: rc = launch_patch_pp<256, 64, 4, 2>(a, pp, grid, stream); break;
-        case 8: rc = launch_patch_pp<128, 128, 2, 2>(a, pp, grid, stream); break;
-        case 9: rc = launch_patch_pp<128, 64, 2, 2>(a, pp, grid, stream); break;
-        case 10: rc = launch_patch_pp<64, 128, 2, 2>(a, pp, grid, stream); break;
-        case 38: rc = launch_patch_pp<128, 64, 4, 2>(a, pp, grid, stream); break;
-        case 39: rc = launch_patch_pp<64, 128, 2, 4>(a, pp, grid, stream); break;
-        case 40: rc = launch_patch_pp<128, 128, 4, 2>(a, pp, grid, stream); break;
-        case 42: rc = launch_patch_pp<256, 128, 8, 2>(a, pp, grid, stream); break;
-        case 43: rc = launch_patch_pp<128, 128, 4, 4>(a, pp, grid, stream); break;
-        default: rc = launch_patch_pp<64, 64, 2, 2>(a, pp, grid, stream); break;
+        case 6: rc = launch_patch_pp<256, 128, 4, 2>(a, pp, grid, stream, sp); break;
+        case 7: rc = launch_patch_pp<256, 64, 4, 2>(a, pp, grid, stream, sp); break;
+        case 8: rc = launch_patch_pp<128, 128, 2, 2>(a, pp, grid, stream, sp); break;
+        case 9: rc = launch_patch_pp<128, 64, 2, 2>(a, pp, grid, stream, sp); break;
+        case 10: rc = launch_patch_pp<64, 128, 2, 2>(a, pp, grid, stream, sp); break;
+        case 38: rc = launch_patch_pp<128, 64, 4, 2>(a, pp, grid, stream, sp); break;
+        case 39: rc = launch_patch_pp<64, 128, 2, 4>(a, pp, grid, stream, sp); break;
+        case 40: rc = launch_patch_pp<128, 128, 4, 2>(a, pp, grid, stream, sp); break;
+        case 42: rc = launch_patch_pp<256, 128, 8, 2>(a, pp, grid, stream, sp); break;
+        case 43: rc = launch_patch_pp<128, 128, 4, 4>(a, pp, grid, stream, sp); break;
+        default: rc = launch_patch_pp<64, 64, 2, 2>(a, pp, grid, stream, sp); break;
     }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("conv3x3_patch_kernel");
-    if (s > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream);
+    if (s > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream, sp);
     return 0;
 }

@@ -37,8 +37,10 @@ using namespace mkdk;
 // a chain of (load latency + barrier) steps with one wave per SIMD: KW groups put KW times the bytes in flight on the CU and cut the
 // chain by KW without the second launch and the fp32 slab traffic of split-K over blocks.
 template <int TM, int TN, int WM, int WN, int CONV, int STAGES, int LN = 0, int GNS = 0, int KW = 1>
-__global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2 pg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = (int)blockIdx.z >= pg.g[0].gz ? 1 : 0;      // grouped launch: the second problem owns the upper half of grid z
+    const GemmArgs& p = pg.g[grp];
     constexpr int XS = TM * 128;          // bytes of one X stage (TM rows x 64 bf16)
     constexpr int WSB = TN * 128;         // bytes of one W stage
     constexpr int STAGE = XS + WSB;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
     char* const smg = smem + kg * (STAGES * STAGE);           // this group's ring
     const int wm = w / WN, wn = w % WN;
     int bx, by, bz;
-    xcd_tile_order(p.xcd_mode, bx, by, bz);
+    xcd_tile_order(p.xcd_mode, p.gz, grp, bx, by, bz);
     const int m0 = bx * TM;
     const int n0 = by * TN;
     const int nk_total = (K + BK - 1) / BK;
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs 
 }
 
 // split-K reduce + epilogue: thread = (row m, 4 columns); slabs summed 4 at a time with independent loads.
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs2 pg) {
+    const GemmArgs& p = pg.g[blockIdx.z];      // grouped launch: z selects the problem
     const int n = (blockIdx.x * 64 + (threadIdx.x & 63)) << 2;
     const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool ok = n < p.N && m < p.M;
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs p) 
 // split-K reduce + epilogue that also emits the GroupNorm statistics of its output: same mapping as splitk_epilogue_kernel
 // (4 rows x 256 columns per block, a wave owns one row, a lane 4 columns); the lane's 8 (sum, sumsq) values go to the block's
 // (sample, group) accumulator in LDS as fixed-point integers (order-free), then one device-scope atomic per entry.
-__global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs2 pg) {
+    const GemmArgs& p = pg.g[blockIdx.z];
     constexpr int CAP = 512;
     __shared__ long long acc[CAP * 2];
     const int tid = threadIdx.x;
@@ -661,14 +665,18 @@ void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cf
 
 static int g_force_cfg = -1;     // tuner / tests only
 static int g_splitk_cap = 0;      // experiment knob (MKD_SPLITK_CAP): 0 = no cap
-void gemm_set_splitk_cap(int cap) { g_splitk_cap = cap; }
+void gemm_set_splitk_cap(int cap) { if (cap != g_splitk_cap) ++g_plan_epoch; g_splitk_cap = cap; }      // (plans hold split-K decisions: re-build)
 // XCD-aware tile order of every launch that does not ask for one itself (MKD_XCD_MODE / mkd_gemm_set_xcd_mode; GemmArgs::xcd_mode).
 // Default 0 = launch order: measured over the whole loop both contiguous-run orders lose (batch 8: 27.61 / 27.28 / 27.51 images/s for
 // 0 / 1 / 2, batch 1: 6.78 / 6.63 / 6.63, 512x512: 9.22 / 9.07 / 9.05; tools/exp_xcd.sh) - with M-tiles fastest and a multiple of 8 of
 // them the launch order already keeps an A tile in one L2, and the weight tiles are small next to 8 x 4 MB of L2.
 static int g_xcd_mode = getenv("MKD_XCD_MODE") ? atoi(getenv("MKD_XCD_MODE")) : 0;
 void gemm_set_xcd_mode(int mode) { g_xcd_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
-void gemm_force_tile_cfg(int cfg) { g_force_cfg = (cfg >= 0 && cfg < N_TILE_CFG) ? cfg : -1; }
+void gemm_force_tile_cfg(int cfg) {
+    const int c = (cfg >= 0 && cfg < N_TILE_CFG) ? cfg : -1;
+    if (c != g_force_cfg) ++g_plan_epoch;       // launch plans hold decisions taken with the previous setting (slab counts of deferred epilogues): re-build
+    g_force_cfg = c;
+}
 
 // Tile + split-K choice.  Large problems take the big tiles (more FLOP per byte staged through L2 -> LDS,
 // which is what bounds these kernels); problems that cannot fill the 256 CUs step down to smaller tiles
@@ -792,7 +800,8 @@ size_t gemm_ws_bytes(int M, int N, int splitk) {
 }
 
 template <int TM, int TN, int WM, int WN, int STAGES, int KW>
-static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
+static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, splitk);
     const size_t lds = (size_t)KW * STAGES * (TM * 128 + TN * 128);
     static bool attr_set[2] = {false, false};
     if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
@@ -801,7 +810,7 @@ static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
         attr_set[a.conv ? 1 : 0] = true;
     }
-    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk * (second ? 2 : 1));
     dim3 block(64 * WM * WN * KW);
     if (a.ln_s) {          // on-the-fly LayerNorm (resolve keeps in-block K split only for that form)
         static bool lattr = false;
@@ -810,17 +819,18 @@ static int launch_tile_kw(const GemmArgs& a, int splitk, hipStream_t stream) {
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
             lattr = true;
         }
-        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1, 0, KW>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1, 0, KW>), grid, block, lds, stream, ag);
         return 0;
     }
-    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
-    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>), grid, block, lds, stream, a);
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 0, KW>), grid, block, lds, stream, ag);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 0, KW>), grid, block, lds, stream, ag);
     return 0;
 }
 
 // plain-epilogue-only launcher (tile configurations 30..37): two instantiations per configuration
 template <int TM, int TN, int WM, int WN, int STAGES>
-static int launch_tile_light(const GemmArgs& a, int splitk, hipStream_t stream) {
+static int launch_tile_light(const GemmArgs& a, int splitk, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, splitk);
     const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (size_t)WN * TM * 2 * sizeof(float);
     static bool attr_set[2] = {false, false};
     if (lds > 64 * 1024 && !attr_set[a.conv ? 1 : 0]) {
@@ -829,15 +839,16 @@ static int launch_tile_light(const GemmArgs& a, int splitk, hipStream_t stream) 
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
         attr_set[a.conv ? 1 : 0] = true;
     }
-    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk * (second ? 2 : 1));
     dim3 block(64 * WM * WN);
-    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
-    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, a);
+    if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, ag);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, ag);
     return 0;
 }
 
 template <int TM, int TN, int WM, int WN, int STAGES>
-static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
+static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, splitk);
     const bool gns = a.gn_stat != nullptr && splitk == 1;
     const size_t lds = (size_t)STAGES * (TM * 128 + TN * 128) + (gns ? (size_t)4096 : (size_t)WN * TM * 2 * sizeof(float));   // ring + tail
     static bool attr_set[2] = {false, false};
@@ -847,7 +858,7 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
         attr_set[a.conv ? 1 : 0] = true;
     }
-    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk);
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk * (second ? 2 : 1));
     dim3 block(64 * WM * WN);
     if (gns) {
         static bool gattr[2] = {false, false};
@@ -857,8 +868,8 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
             gattr[a.conv ? 1 : 0] = true;
         }
-        if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 1>), grid, block, lds, stream, a);
-        else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 1>), grid, block, lds, stream, a);
+        if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES, 0, 1>), grid, block, lds, stream, ag);
+        else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 0, 1>), grid, block, lds, stream, ag);
         return 0;
     }
     if (a.ln_s && !a.stat_in) {          // LayerNorm statistics taken by the GEMM itself
@@ -868,7 +879,7 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
             lf_attr = true;
         }
-        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, -1>), grid, block, lds, stream, ag);
         return 0;
     }
     if (a.ln_s) {
@@ -880,15 +891,30 @@ static int launch_tile(const GemmArgs& a, int splitk, hipStream_t stream) {
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
             ln_attr = true;
         }
-        if (a.stat_in_slots <= 4) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 1>), grid, block, lds, stream, a);
-        else if (a.stat_in_slots <= 12) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 3>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 5>), grid, block, lds, stream, a);
-    } else if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, a);
-    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, a);
+        if (a.stat_in_slots <= 4) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 1>), grid, block, lds, stream, ag);
+        else if (a.stat_in_slots <= 12) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 3>), grid, block, lds, stream, ag);
+        else hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES, 5>), grid, block, lds, stream, ag);
+    } else if (a.conv) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, STAGES>), grid, block, lds, stream, ag);
+    else        hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, STAGES>), grid, block, lds, stream, ag);
     return 0;
 }
 
-int launch_gemm(GemmArgs a, hipStream_t stream) {
+bool gemm_same_geometry(const GemmArgs& a, const GemmArgs& b) {
+    return a.M == b.M && a.N == b.N && a.K == b.K && a.lda == b.lda && a.ldw == b.ldw && a.conv == b.conv && a.Hin == b.Hin && a.Win == b.Win &&
+           a.Cin == b.Cin && a.Hout == b.Hout && a.Wout == b.Wout && a.stride == b.stride && a.up == b.up && a.splitk == b.splitk &&
+           a.out_f32 == b.out_f32 && a.act == b.act && a.ldc == b.ldc && a.defer_epilogue == b.defer_epilogue && a.rows_per_batch == b.rows_per_batch &&
+           (a.ln_s != nullptr) == (b.ln_s != nullptr) && a.ln_eps == b.ln_eps && !a.stat_in && !b.stat_in && !a.stat_out && !b.stat_out &&
+           !a.gn_stat && !b.gn_stat && (a.R != nullptr) == (b.R != nullptr) && a.ldr == b.ldr && (a.rowbias != nullptr) == (b.rowbias != nullptr) &&
+           (a.bias != nullptr) == (b.bias != nullptr);
+}
+
+int launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second) {
+    GemmArgs b;
+    if (second) {
+        if (!gemm_same_geometry(a, *second)) return mkd_fail(-1, "gemm: a grouped launch needs two problems of identical geometry");
+        if (!second->A || !second->W || !second->C) return mkd_fail(-1, "gemm: grouped launch with a null operand");
+        b = *second; b.zero = a.zero;
+    }
     if (!a.xcd_mode) a.xcd_mode = g_xcd_mode;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mkd_fail(-1, "gemm: empty problem");
     if (a.N % 4) return mkd_fail(-1, "gemm: N must be a multiple of 4");
@@ -907,68 +933,76 @@ int launch_gemm(GemmArgs a, hipStream_t stream) {
         return mkd_fail(-1, "gemm: GroupNorm statistics need a plain bf16 output, rows per sample, channels per group, <= 32 groups");
     GemmPlan g;
     { const int rc = gemm_resolve_plan(a, &g); if (rc) return rc; }
-    if (is_patch_cfg(g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream);
-    if (g.splitk > 1 && !a.ws) return mkd_fail(-1, "gemm: split-K needs a workspace");
+    if (a.defer_epilogue && !is_patch_cfg(g.cfg) && (g.splitk < 2 || (a.expect_splitk > 0 && g.splitk != a.expect_splitk)))
+        return mkd_fail(-3, "gemm: deferred split-K epilogue planned for " + std::to_string(a.expect_splitk) + " slabs, the launch resolves to " +
+                                std::to_string(g.splitk) + " (tile / split-K settings changed after mkd_prepare: prepare again)");
+    if (is_patch_cfg(g.cfg)) return launch_conv_patch(a, g.cfg, g.splitk, stream, second ? &b : nullptr);
+    if (g.splitk > 1 && (!a.ws || (second && (!b.ws || b.ws == a.ws)))) return mkd_fail(-1, "gemm: split-K needs a workspace (one per problem)");
+    if (second && g.splitk > 1 && gemm_ws_bytes(b.M, b.N, g.splitk) > b.ws_bytes) return mkd_fail(-1, "gemm: split-K workspace of the second problem too small");
     if (g.splitk > 1 && gemm_ws_bytes(a.M, a.N, g.splitk) > a.ws_bytes)
         return mkd_fail(-1, "gemm: split-K workspace too small (" + std::to_string(a.ws_bytes) + " B for " + std::to_string(g.splitk) + " slabs of " +
                                 std::to_string(a.M) + " x " + std::to_string(a.N) + ")");
     a.splitk = g.splitk;
     a.ksteps_per_split = g.per;
+    const GemmArgs* const sp = second ? &b : nullptr;
+    if (second) { b.splitk = a.splitk; b.ksteps_per_split = a.ksteps_per_split; b.xcd_mode = a.xcd_mode; }
     int rc;
     switch (g.cfg) {
-        case 0: rc = launch_tile<256, 128, 4, 2, 3>(a, g.splitk, stream); break;
-        case 1: rc = launch_tile<128, 128, 2, 2, 3>(a, g.splitk, stream); break;
-        case 2: rc = launch_tile<128, 128, 2, 2, 2>(a, g.splitk, stream); break;
-        case 3: rc = launch_tile<128, 64, 2, 2, 3>(a, g.splitk, stream); break;
-        case 4: rc = launch_tile<64, 128, 2, 2, 3>(a, g.splitk, stream); break;
-        case 12: rc = launch_tile<64, 64, 2, 2, 6>(a, g.splitk, stream); break;
-        case 13: rc = launch_tile<64, 128, 2, 2, 5>(a, g.splitk, stream); break;
-        case 14: rc = launch_tile<64, 160, 2, 2, 3>(a, g.splitk, stream); break;
-        case 15: rc = launch_tile<128, 160, 2, 2, 3>(a, g.splitk, stream); break;
-        case 16: rc = launch_tile<64, 160, 2, 2, 2>(a, g.splitk, stream); break;
-        case 17: rc = launch_tile<32, 64, 2, 2, 4>(a, g.splitk, stream); break;
-        case 18: rc = launch_tile<64, 32, 2, 2, 4>(a, g.splitk, stream); break;
-        case 19: rc = launch_tile<32, 32, 2, 2, 4>(a, g.splitk, stream); break;
-        case 20: rc = launch_tile_kw<32, 32, 2, 2, 4, 2>(a, g.splitk, stream); break;
-        case 21: rc = launch_tile_kw<32, 32, 2, 2, 4, 4>(a, g.splitk, stream); break;
-        case 22: rc = launch_tile_kw<64, 32, 2, 2, 4, 2>(a, g.splitk, stream); break;
-        case 23: rc = launch_tile_kw<64, 32, 2, 2, 3, 4>(a, g.splitk, stream); break;
-        case 24: rc = launch_tile_kw<64, 64, 2, 2, 4, 2>(a, g.splitk, stream); break;
-        case 25: rc = launch_tile_kw<64, 64, 2, 2, 2, 4>(a, g.splitk, stream); break;
-        case 26: rc = launch_tile_kw<32, 64, 2, 2, 4, 2>(a, g.splitk, stream); break;
-        case 27: rc = launch_tile_kw<32, 64, 2, 2, 3, 4>(a, g.splitk, stream); break;
-        case 28: rc = launch_tile_kw<128, 64, 2, 2, 3, 2>(a, g.splitk, stream); break;
-        case 29: rc = launch_tile_kw<64, 128, 2, 2, 3, 2>(a, g.splitk, stream); break;
-        case 30: rc = launch_tile_light<64, 64, 2, 2, 2>(a, g.splitk, stream); break;
-        case 31: rc = launch_tile_light<128, 64, 2, 2, 2>(a, g.splitk, stream); break;
-        case 32: rc = launch_tile_light<64, 128, 2, 2, 2>(a, g.splitk, stream); break;
-        case 33: rc = launch_tile_light<64, 32, 2, 2, 2>(a, g.splitk, stream); break;
-        case 34: rc = launch_tile_light<128, 128, 4, 2, 2>(a, g.splitk, stream); break;
-        case 35: rc = launch_tile_light<128, 64, 4, 2, 3>(a, g.splitk, stream); break;
-        case 36: rc = launch_tile_light<64, 128, 2, 4, 3>(a, g.splitk, stream); break;
-        case 37: rc = launch_tile_light<64, 64, 2, 4, 4>(a, g.splitk, stream); break;
-        case 41: rc = launch_tile_light<256, 64, 4, 2, 3>(a, g.splitk, stream); break;
-        default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream); break;
+        case 0: rc = launch_tile<256, 128, 4, 2, 3>(a, g.splitk, stream, sp); break;
+        case 1: rc = launch_tile<128, 128, 2, 2, 3>(a, g.splitk, stream, sp); break;
+        case 2: rc = launch_tile<128, 128, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 3: rc = launch_tile<128, 64, 2, 2, 3>(a, g.splitk, stream, sp); break;
+        case 4: rc = launch_tile<64, 128, 2, 2, 3>(a, g.splitk, stream, sp); break;
+        case 12: rc = launch_tile<64, 64, 2, 2, 6>(a, g.splitk, stream, sp); break;
+        case 13: rc = launch_tile<64, 128, 2, 2, 5>(a, g.splitk, stream, sp); break;
+        case 14: rc = launch_tile<64, 160, 2, 2, 3>(a, g.splitk, stream, sp); break;
+        case 15: rc = launch_tile<128, 160, 2, 2, 3>(a, g.splitk, stream, sp); break;
+        case 16: rc = launch_tile<64, 160, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 17: rc = launch_tile<32, 64, 2, 2, 4>(a, g.splitk, stream, sp); break;
+        case 18: rc = launch_tile<64, 32, 2, 2, 4>(a, g.splitk, stream, sp); break;
+        case 19: rc = launch_tile<32, 32, 2, 2, 4>(a, g.splitk, stream, sp); break;
+        case 20: rc = launch_tile_kw<32, 32, 2, 2, 4, 2>(a, g.splitk, stream, sp); break;
+        case 21: rc = launch_tile_kw<32, 32, 2, 2, 4, 4>(a, g.splitk, stream, sp); break;
+        case 22: rc = launch_tile_kw<64, 32, 2, 2, 4, 2>(a, g.splitk, stream, sp); break;
+        case 23: rc = launch_tile_kw<64, 32, 2, 2, 3, 4>(a, g.splitk, stream, sp); break;
+        case 24: rc = launch_tile_kw<64, 64, 2, 2, 4, 2>(a, g.splitk, stream, sp); break;
+        case 25: rc = launch_tile_kw<64, 64, 2, 2, 2, 4>(a, g.splitk, stream, sp); break;
+        case 26: rc = launch_tile_kw<32, 64, 2, 2, 4, 2>(a, g.splitk, stream, sp); break;
+        case 27: rc = launch_tile_kw<32, 64, 2, 2, 3, 4>(a, g.splitk, stream, sp); break;
+        case 28: rc = launch_tile_kw<128, 64, 2, 2, 3, 2>(a, g.splitk, stream, sp); break;
+        case 29: rc = launch_tile_kw<64, 128, 2, 2, 3, 2>(a, g.splitk, stream, sp); break;
+        case 30: rc = launch_tile_light<64, 64, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 31: rc = launch_tile_light<128, 64, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 32: rc = launch_tile_light<64, 128, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 33: rc = launch_tile_light<64, 32, 2, 2, 2>(a, g.splitk, stream, sp); break;
+        case 34: rc = launch_tile_light<128, 128, 4, 2, 2>(a, g.splitk, stream, sp); break;
+        case 35: rc = launch_tile_light<128, 64, 4, 2, 3>(a, g.splitk, stream, sp); break;
+        case 36: rc = launch_tile_light<64, 128, 2, 4, 3>(a, g.splitk, stream, sp); break;
+        case 37: rc = launch_tile_light<64, 64, 2, 4, 4>(a, g.splitk, stream, sp); break;
+        case 41: rc = launch_tile_light<256, 64, 4, 2, 3>(a, g.splitk, stream, sp); break;
+        default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream, sp); break;
     }
     if (rc) return rc;
     MKD_LAUNCH_CHECK("gemm_kernel");
-    if (g.splitk > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream);
+    if (g.splitk > 1 && !a.defer_epilogue) return launch_splitk_epilogue(a, stream, sp);
     return 0;
 }
 
-int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream) {
+int launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, 1);
+    const int gz = second ? 2 : 1;
 #ifdef MKD_EXP_ABLATE
     static const int skip = getenv("MKD_EXP_SKIP") ? atoi(getenv("MKD_EXP_SKIP")) : 0;      // experiment build only: 8 = no split-K reduce launches (WRONG results)
     if (skip & 8) return 0;
 #endif
     if (a.gn_stat) {
-        dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
-        hipLaunchKernelGGL(splitk_epilogue_gn_kernel, rg, dim3(256), 0, stream, a);
+        dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4, gz);
+        hipLaunchKernelGGL(splitk_epilogue_gn_kernel, rg, dim3(256), 0, stream, ag);
         MKD_LAUNCH_CHECK("splitk_epilogue_gn_kernel");
         return 0;
     }
-    dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, a);
+    dim3 rg((a.N / 4 + 63) / 64, (a.M + 3) / 4, gz);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, rg, dim3(256), 0, stream, ag);
     MKD_LAUNCH_CHECK("splitk_epilogue_kernel");
     return 0;
 }

@@ -1,6 +1,7 @@
 // Small HBM-bound kernels of the path: DDIM update (+CFG combine), GEGLU, sinusoidal timestep
 // embedding, the three tiny-channel 3x3 convs (4->C, 6->16, C->4), weight packing, layout glue.
 #include "mkd_common.h"
+#include <cstring>
 
 namespace {
 
@@ -28,23 +29,38 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
 // ---- device-resident step state for hipGraph replay of the DDIM loop -------------------------------------
 // One graph = one reverse step; what changes between steps (timestep, schedule coefficients) is read from
 // device tables through a counter that the first kernel of the graph advances, so the SAME graph replays.
-__global__ void step_setup_kernel(StepState* st, int64_t* t_out, int batch) {
-    __shared__ int idx;
-    if (threadIdx.x == 0) idx = st->counter;
-    __syncthreads();
-    const int i = idx;
-    for (int b = threadIdx.x; b < batch; b += blockDim.x) t_out[b] = st->timesteps[i];
-    if (threadIdx.x == 0) {
-        st->cur[0] = st->coef[4 * i + 0]; st->cur[1] = st->coef[4 * i + 1];
-        st->cur[2] = st->coef[4 * i + 2]; st->cur[3] = st->coef[4 * i + 3];
-        st->counter = i - 1;
+__device__ __forceinline__ void temb_copy_rows(const TembSel& ts, int step, int gtid, int gthreads) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int nv = ts.n[k] >> 2;
+        if (!nv) continue;
+        const f32x4* src = (const f32x4*)(ts.tab[k] + (size_t)step * ts.n[k]);
+        f32x4* dst = (f32x4*)ts.proj[k];
+        for (int i = gtid; i < nv * ts.batch; i += gthreads) dst[i] = src[i % nv];
     }
 }
 
-// in-place x <- x_{t-1} (eta == 0), coefficients from the step state
+__global__ void step_setup_kernel(StepState* st, int64_t* t_out, int batch, const TembSel ts) {
+    const int i = st->counter;          // read-only in this kernel: ddim_step_state_kernel, the step's last, advances it
+    if (blockIdx.x == 0) {
+        for (int b = threadIdx.x; b < batch; b += blockDim.x) t_out[b] = st->timesteps[i];
+        if (threadIdx.x == 0) {
+            st->cur[0] = st->coef[4 * i + 0]; st->cur[1] = st->coef[4 * i + 1];
+            st->cur[2] = st->coef[4 * i + 2]; st->cur[3] = st->coef[4 * i + 3];
+        }
+    }
+    temb_copy_rows(ts, i, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+__global__ void temb_select_kernel(const TembSel ts, int step) {
+    temb_copy_rows(ts, step, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// in-place x <- x_{t-1} (eta == 0), coefficients from the step state; ends the step: the counter moves to the next one
 __global__ void ddim_step_state_kernel(float* __restrict__ x, const float* __restrict__ eps_c, const float* __restrict__ eps_u,
-                                       float cfg_scale, const StepState* __restrict__ st, int64_t n) {
+                                       float cfg_scale, StepState* __restrict__ st, int64_t n) {
     const float sqrt_at_inv = st->cur[0], sqrt_aprev = st->cur[1], dir_coef = st->cur[2], s1m = st->cur[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->counter = st->counter - 1;      // (nothing else in this kernel reads it)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float e = eps_c[i];
         if (eps_u) { const float u = eps_u[i]; e = u + cfg_scale * (e - u); }
@@ -124,10 +140,11 @@ __global__ void conv3x3_direct_kernel(const void* __restrict__ xin, int in_nchw_
 // ---- 3x3 conv with a tiny Cin read from fp32 NCHW (the 4 -> 320 input conv): thread = output channel, the
 // thread's 9*CIN weights live in registers, a block walks pixels with the 9*CIN input patch shared through LDS.
 template <int CIN>
-__global__ __launch_bounds__(512) void conv3x3_fewin_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
-                                                            const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                            const bf16_t* __restrict__ add, int act, int batch, int H, int W,
+__global__ __launch_bounds__(512) void conv3x3_fewin_kernel(const float* __restrict__ x, const Pair<ConvInIo> io, int act, int batch, int H, int W,
                                                             int Cout, int pix_per_block) {
+    // grouped launch: grid y selects the problem (both nets convolve the SAME x with their own weights)
+    const bf16_t* __restrict__ const w = io.g[blockIdx.y].w; const float* __restrict__ const bias = io.g[blockIdx.y].bias;
+    bf16_t* __restrict__ const y = io.g[blockIdx.y].y; const bf16_t* __restrict__ const add = io.g[blockIdx.y].add;
     constexpr int KK = 9 * CIN;
     constexpr int PPB_MAX = 16;
     __shared__ float patch[PPB_MAX][KK];
@@ -386,17 +403,21 @@ int launch_timestep_embedding(const int64_t* t, bf16_t* out, int batch, int dim,
 
 int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
-                          int Cin, int Cout, int stride, hipStream_t stream) {
+                          int Cin, int Cout, int stride, hipStream_t stream, const ConvInIo* second) {
     if (stride != 1 && stride != 2) return mkd_fail(-1, "conv3x3_direct: stride must be 1 or 2");
     if (in_nchw_f32 && !out_nchw_f32 && stride == 1 && Cin == 4 && Cout >= 64 && Cout <= 512) {
         const int npix = batch * Hin * Win;
         const int ppb = 16;            // <= PPB_MAX of the kernel
         const int threads = (Cout + 63) / 64 * 64;
-        hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, dim3((npix + ppb - 1) / ppb), dim3(threads), 0, stream, (const float*)x, w, bias,
-                           (bf16_t*)y, add, act, batch, Hin, Win, Cout, ppb);
+        Pair<ConvInIo> io;
+        io.g[0] = ConvInIo{w, bias, (bf16_t*)y, add};
+        io.g[1] = second ? *second : io.g[0];
+        hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, dim3((npix + ppb - 1) / ppb, second ? 2 : 1), dim3(threads), 0, stream, (const float*)x, io,
+                           act, batch, Hin, Win, Cout, ppb);
         MKD_LAUNCH_CHECK("conv3x3_fewin_kernel");
         return 0;
     }
+    if (second) return mkd_fail(-1, "conv3x3_direct: only the 4 -> C input convolution has a grouped form");
     if (!in_nchw_f32 && out_nchw_f32 && (Cout == 4 || Cout == 3) && stride == 1 && act == 0 && !add && Cin % 8 == 0) {
         const int npix = batch * Hin * Win;
         if (Cout == 4)
@@ -471,13 +492,29 @@ int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream) {
     return 0;
 }
 
-int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream) {
-    hipLaunchKernelGGL(step_setup_kernel, dim3(1), dim3(64), 0, stream, st, t_out, batch);
+static int temb_blocks(const TembSel& ts) {
+    const long long v = ((long long)(ts.n[0] >> 2) + (ts.n[1] >> 2)) * ts.batch;
+    long long b = (v + 1023) / 1024;          // ~4 float4 per thread
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+int launch_temb_select(const TembSel& ts, int step, hipStream_t stream) {
+    if ((ts.n[0] | ts.n[1]) & 3) return mkd_fail(-1, "temb_select: row lengths must be multiples of 4");
+    if (!ts.n[0] && !ts.n[1]) return 0;
+    hipLaunchKernelGGL(temb_select_kernel, dim3(temb_blocks(ts)), dim3(256), 0, stream, ts, step);
+    MKD_LAUNCH_CHECK("temb_select_kernel");
+    return 0;
+}
+int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream, const TembSel* tsp) {
+    TembSel ts; memset(&ts, 0, sizeof(ts));
+    if (tsp) ts = *tsp;
+    if ((ts.n[0] | ts.n[1]) & 3) return mkd_fail(-1, "step_setup: row lengths must be multiples of 4");
+    const int blocks = (ts.n[0] || ts.n[1]) ? temb_blocks(ts) : 1;
+    hipLaunchKernelGGL(step_setup_kernel, dim3(blocks), dim3(256), 0, stream, st, t_out, batch, ts);
     MKD_LAUNCH_CHECK("step_setup_kernel");
     return 0;
 }
 
-int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, const StepState* st, int64_t n,
+int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, StepState* st, int64_t n,
                            hipStream_t stream) {
     hipLaunchKernelGGL(ddim_step_state_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, cfg_scale, st, n);
     MKD_LAUNCH_CHECK("ddim_step_state_kernel");

@@ -125,11 +125,12 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t*
 // slabs that do not fit the register budget (second pass re-reads, L2 hit).  Statistics: per-thread fp32 sums ->
 // LDS -> fixed-shape tree over the pixel lanes (deterministic) -> per-group mean / rstd.
 template <int NV>
-__global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const bf16_t* __restrict__ x, int ld_in, bf16_t* __restrict__ y,
-                                                        int ld_out, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, int silu, int hw,
+__global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const Pair<NormIo> io, int ld_in, int ld_out, float eps, int silu, int hw,
                                                         int C, int groups, int gpb) {
     extern __shared__ __attribute__((aligned(16))) float s_red[];    // [2][NT][8] then per-channel / per-group
+    // grouped launch: grid z selects the problem (same geometry, own tensors and affine parameters)
+    const bf16_t* __restrict__ const x = io.g[blockIdx.z].x; bf16_t* __restrict__ const y = io.g[blockIdx.z].y;
+    const float* __restrict__ const gamma = io.g[blockIdx.z].gamma; const float* __restrict__ const beta = io.g[blockIdx.z].beta;
     const int cg = C / groups;
     const int nch = gpb * cg;                 // channels of this block (multiple of 8)
     const int V = nch >> 3;
@@ -307,10 +308,12 @@ struct SlabGn {
 };
 
 template <int NV>
-__global__ __launch_bounds__(512) void gn_slab_kernel(const SlabGn a, bf16_t* __restrict__ y, int ld_out,
-                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(512) void gn_slab_kernel(const Pair<SlabGn> ag, const Pair<NormIo> io, int ld_out,
                                                                        float eps, int silu, int hw, int C, int groups, int gpb) {
     extern __shared__ __attribute__((aligned(16))) float s_red[];
+    const SlabGn& a = ag.g[blockIdx.z];          // grouped launch: grid z selects the problem
+    bf16_t* __restrict__ const y = io.g[blockIdx.z].y;
+    const float* __restrict__ const gamma = io.g[blockIdx.z].gamma; const float* __restrict__ const beta = io.g[blockIdx.z].beta;
     const int cg = C / groups;
     const int nch = gpb * cg;                 // channels of this block (multiple of 8, cg >= 8: launcher)
     const int V = nch >> 3;
@@ -556,9 +559,9 @@ __global__ __launch_bounds__(320) void gn_colstats_kernel(const bf16_t* __restri
 
 // one wave per row; NV = vectors of 8 per lane (d <= 64*8*NV)
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps,
-                                                        bf16_t* __restrict__ y, int rows, int d, int ldx) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const Pair<NormIo> io, float eps, int rows, int d, int ldx) {
+    const bf16_t* __restrict__ const x = io.g[blockIdx.y].x; bf16_t* __restrict__ const y = io.g[blockIdx.y].y;      // grouped launch: grid y selects the problem
+    const float* __restrict__ const gamma = io.g[blockIdx.y].gamma; const float* __restrict__ const beta = io.g[blockIdx.y].beta;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -652,8 +655,11 @@ size_t groupnorm_partials_bytes(int batch, int hw, int groups) {
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
-                     hipStream_t stream) {
+                     hipStream_t stream, const NormIo* second) {
     if (C % 8 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C, ld must be multiples of 8");
+    Pair<NormIo> io;
+    io.g[0] = NormIo{x, y, gamma, beta};
+    io.g[1] = second ? *second : io.g[0];
     if (groups > GN_MAX_GROUPS || groups <= 0 || C % groups) return mkd_fail(-1, "groupnorm: bad group count");
     if (!partials) return mkd_fail(-1, "groupnorm: partials workspace missing");
     // single-launch path: smallest group chunk whose channel span is a multiple of 8, slab small enough to
@@ -678,10 +684,9 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                 else if (per_of(1024) <= 8) { nt = 1024; per = per_of(1024); }
                 else { nt = 256; per = 1 << 20; }
                 const size_t lds = (size_t)(2 * nt * 8 + 2 * nch + 2 * gpb) * sizeof(float);
-                dim3 grid(groups / gpb, batch);
+                dim3 grid(groups / gpb, batch, second ? 2 : 1);
 #define MKD_GN_LAUNCH(NVV)                                                                                              \
-    hipLaunchKernelGGL(gn_fused_kernel<NVV>, grid, dim3(nt), lds, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu, hw, C, \
-                       groups, gpb)
+    hipLaunchKernelGGL(gn_fused_kernel<NVV>, grid, dim3(nt), lds, stream, io, ld_in, ld_out, eps, silu, hw, C, groups, gpb)
                 if (per <= 4) MKD_GN_LAUNCH(4);
                 else if (per <= 8) MKD_GN_LAUNCH(8);
                 else if (per <= 16) MKD_GN_LAUNCH(16);
@@ -691,6 +696,11 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                 return 0;
             }
         }
+    }
+    if (second) {          // the two-kernel path is not grouped: one problem after the other (they share the partials workspace)
+        int rc = launch_groupnorm(x, ld_in, gamma, beta, eps, silu, y, ld_out, batch, hw, C, groups, partials, stream, nullptr);
+        if (rc) return rc;
+        return launch_groupnorm(second->x, ld_in, second->gamma, second->beta, eps, silu, second->y, ld_out, batch, hw, C, groups, partials, stream, nullptr);
     }
     const int V = C / 8;
     if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");
@@ -732,19 +742,35 @@ bool gn_from_slabs_supported(int batch, int hw, int C) {
     return batch > 0 && C % 8 == 0 && gn_slab_shape(hw, C, &gpb, &nt, &per);
 }
 
-int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
-                         int batch, int hw, hipStream_t stream) {
-    int gpb, nt, per;
-    if (!gn_slab_shape(hw, a.N, &gpb, &nt, &per)) return mkd_fail(-4, "gn_from_slabs: geometry does not fit the single-pass kernel");
+static int slab_args(const GemmArgs& a, int batch, int hw, int ld_out, SlabGn* out) {
     if (a.splitk < 2 || !a.ws || a.M != batch * hw || a.N % 8 || ld_out % 8 || a.out_f32 || a.act != 0 || (a.R && a.ldr % 8) ||
         (a.C && a.ldc % 8) || (a.rowbias && a.rows_per_batch != hw))
         return mkd_fail(-1, "gn_from_slabs: needs split-K slabs of a plain bf16 GEMM with one row bias per sample");
     SlabGn sg;
     sg.ws = a.ws; sg.splitk = a.splitk; sg.M = a.M; sg.N = a.N; sg.bias = a.bias; sg.rowbias = a.rowbias; sg.ldrb = a.ldrb;
     sg.rpb = a.rows_per_batch > 0 ? a.rows_per_batch : 1; sg.scale = a.scale; sg.R = a.R; sg.ldr = a.ldr; sg.raw = (bf16_t*)a.C; sg.ldraw = a.ldc;
+    *out = sg;
+    return 0;
+}
+
+int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
+                         int batch, int hw, hipStream_t stream, const GemmArgs* a2, const NormIo* second) {
+    int gpb, nt, per;
+    if (!gn_slab_shape(hw, a.N, &gpb, &nt, &per)) return mkd_fail(-4, "gn_from_slabs: geometry does not fit the single-pass kernel");
+    if ((a2 != nullptr) != (second != nullptr)) return mkd_fail(-1, "gn_from_slabs: a grouped launch needs both the second GEMM and the second GroupNorm");
+    Pair<SlabGn> sg;
+    Pair<NormIo> io;
+    int rc = slab_args(a, batch, hw, ld_out, &sg.g[0]); if (rc) return rc;
+    io.g[0] = NormIo{nullptr, y, gamma, beta};
+    sg.g[1] = sg.g[0]; io.g[1] = io.g[0];
+    if (a2) {
+        if (a2->M != a.M || a2->N != a.N || a2->splitk != a.splitk || a2->ws == a.ws) return mkd_fail(-1, "gn_from_slabs: grouped problems must share the geometry and own their slabs");
+        rc = slab_args(*a2, batch, hw, ld_out, &sg.g[1]); if (rc) return rc;
+        io.g[1] = *second;
+    }
     const size_t lds = (size_t)(2 * (nt / 64) * gpb + 2 * gpb) * sizeof(float);
-    dim3 grid(32 / gpb, batch);
-#define MKD_GNS_LAUNCH(NVV) hipLaunchKernelGGL(gn_slab_kernel<NVV>, grid, dim3(nt), lds, stream, sg, y, ld_out, gamma, beta, eps, silu, hw, a.N, 32, gpb)
+    dim3 grid(32 / gpb, batch, a2 ? 2 : 1);
+#define MKD_GNS_LAUNCH(NVV) hipLaunchKernelGGL(gn_slab_kernel<NVV>, grid, dim3(nt), lds, stream, sg, io, ld_out, eps, silu, hw, a.N, 32, gpb)
     if (per <= 4) MKD_GNS_LAUNCH(4);
     else if (per <= 8) MKD_GNS_LAUNCH(8);
     else MKD_GNS_LAUNCH(16);
@@ -792,15 +818,18 @@ int launch_gn_colstats(const bf16_t* x, int ld, int batch, int hw, int ncols, in
 }
 
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
-                     int rows, int d, hipStream_t stream, int ldx) {
+                     int rows, int d, hipStream_t stream, int ldx, const NormIo* second) {
     if (ldx <= 0) ldx = d;
     if (d % 8 || ldx % 8) return mkd_fail(-1, "layernorm: d and the row stride must be multiples of 8");
     const int V = d / 8;
-    dim3 grid((rows + 3) / 4);
-    if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
-    else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
-    else if (V <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
-    else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, d, ldx);
+    Pair<NormIo> io;
+    io.g[0] = NormIo{x, y, gamma, beta};
+    io.g[1] = second ? *second : io.g[0];
+    dim3 grid((rows + 3) / 4, second ? 2 : 1);
+    if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);
+    else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);
+    else if (V <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);
+    else if (V <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);
     else return mkd_fail(-4, "layernorm: d > 2048 unsupported");
     MKD_LAUNCH_CHECK("layernorm_kernel");
     return 0;

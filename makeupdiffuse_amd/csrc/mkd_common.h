@@ -86,11 +86,26 @@ struct GemmArgs {
     // gn_cg channels per group OF THE CONSUMER's tensor, gn_coff = column of this output inside it (concat halves), gn_hw rows per sample
     long long* gn_stat; int gn_cg; int gn_coff; int gn_hw;
     int defer_epilogue;                     // split-K launches: leave the fp32 partial slabs in ws; the caller's next kernel reduces them (launch_gn_from_slabs)
+    int expect_splitk;                      // ... which was planned for exactly this many slabs: the launch fails if it resolves to another count (0: unchecked)
     // workgroup -> tile order for the 8 XCDs (workgroups are dealt round-robin to them in launch order, each XCD has its own L2):
     // 0 launch order; 1 an XCD owns runs of M-tiles of one N-tile (the weight tile lives in ONE L2); 2 runs of N-tiles of one M-tile
     int xcd_mode;
+    int gz;               // z extent of ONE problem's grid (set by the launchers); a grouped launch stacks the second problem above it
     const bf16_t* zero;   // >= 16 bytes of zeros
 };
+
+// ---------------------------------------------------------------------------------------------
+// Grouped launches.  The ControlNet and the UNet encoder + middle block (reference diffmk/makeup_diffuse.py:164-168: the two
+// calls of apply_model) run the SAME op sequence on identical shapes with different weights / inputs.  One launch can carry both
+// problems: the kernel's argument block is a 2-entry table and a grid coordinate (z, or y for 1-D grids) selects the entry, so
+// the pair costs ONE dependent dispatch instead of two on two contending queues.  Same kernels, same tiles, same order of
+// operations per output: results are bit-identical to two separate launches.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Pair { T g[2]; };
+typedef Pair<GemmArgs> GemmArgs2;
+struct NormIo { const bf16_t* x; bf16_t* y; const float* gamma; const float* beta; };     // GroupNorm / LayerNorm operands of one problem
+struct AttnIo { const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; };
+struct ConvInIo { const bf16_t* w; const float* bias; bf16_t* y; const bf16_t* add; };     // 4 -> C input convolution (same x for both nets)
 
 // device-resident DDIM step state (hipGraph replay): tables of n_steps entries, counter runs n_steps-1 .. 0
 constexpr int MKD_MAX_STEPS = 1024;
@@ -101,8 +116,14 @@ struct StepState {
     float coef[4 * MKD_MAX_STEPS];
 };
 
+// Time embedding of a sampling call: row `step` of tab[k] ([steps, n[k]] fp32, one table per net) is copied into every one of
+// the `batch` rows of proj[k] ([batch, n[k]]: what the ResBlock epilogues read as their per-sample row bias).  n[k] % 4 == 0; n[k] = 0: absent.
+struct TembSel { const float* tab[2]; float* proj[2]; int n[2]; int batch; };
+
 // launchers (each only enqueues on `stream`)
-int  launch_gemm(GemmArgs a, hipStream_t stream);                  // picks tile + split-K (a.splitk==0: auto)
+// picks tile + split-K (a.splitk==0: auto).  second != null: grouped launch of two problems of identical geometry (see Pair)
+int  launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second = nullptr);
+bool gemm_same_geometry(const GemmArgs& a, const GemmArgs& b);     // may the two run as one grouped launch?
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
 int  gemm_resolve(const GemmArgs& a, int* cfg, int* splitk);       // the (tile, split-K) launch_gemm will use for exactly these arguments
 int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
@@ -114,14 +135,14 @@ void gemm_set_override(int M, int N, int K, int conv, int stride, int up, int cf
 int  gemm_plan_epoch();                       // bumped by every override change: launch plans re-build on the next mkd_prepare
 int  gemm_num_tile_cfgs();
 const char* gemm_tile_cfg_name(int cfg);
-int  launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream);
+int  launch_splitk_epilogue(const GemmArgs& a, hipStream_t stream, const GemmArgs* second = nullptr);
 bool conv_patch_supported(const GemmArgs& a, int cfg);
-int  launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream);
+int  launch_conv_patch(GemmArgs a, int cfg, int splitk, hipStream_t stream, const GemmArgs* second = nullptr);
 size_t gemm_ws_bytes(int M, int N, int splitk);
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
-                     hipStream_t stream);
+                     hipStream_t stream, const NormIo* second = nullptr);      // second: same geometry, grouped launch
 size_t groupnorm_partials_bytes(int batch, int hw, int groups);
 // GroupNorm with producer-emitted statistics (gstat[batch][32][2] int64 fixed point, see gemm_device.h): element-wise apply,
 // and the stand-alone producer of the same statistics for tensors whose writer cannot emit them
@@ -132,22 +153,22 @@ int launch_gn_apply_stats(const bf16_t* x, int ld_in, const float* gamma, const 
 // output is also stored when a.C is non-null.  a = the GEMM's arguments with ws / splitk as launch_gemm resolved them.
 // Returns -4 when the geometry does not fit the single-pass kernel (the caller then runs the two kernels separately).
 int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
-                         int batch, int hw, hipStream_t stream);
+                         int batch, int hw, hipStream_t stream, const GemmArgs* a2 = nullptr, const NormIo* second = nullptr);
 bool gn_from_slabs_supported(int batch, int hw, int C);
 int launch_gn_colstats(const bf16_t* x, int ld, int batch, int hw, int ncols, int cg, int coff, long long* gstat, hipStream_t stream);
 int launch_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int N, int K,
                           bf16_t* w_out, int dst_row0, int dst_row_mul, float* s_out, float* b_out, hipStream_t stream);
 int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, float eps, bf16_t* y,
-                     int rows, int d, hipStream_t stream, int ldx = 0);      // ldx: input row stride (0 = d); y is dense
+                     int rows, int d, hipStream_t stream, int ldx = 0, const NormIo* second = nullptr);      // ldx: input row stride (0 = d); y is dense
 int launch_merge_ff_out(const float* P, const float* W2, const float* b2, const float* bp, bf16_t* Wm, float* bias_m, int d,
                         hipStream_t stream);
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
-                     hipStream_t stream, int causal = 0);
+                     hipStream_t stream, int causal = 0, const AttnIo* second = nullptr);
 int launch_geglu(const bf16_t* x, bf16_t* y, int rows, int inner, hipStream_t stream);
 int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,
-                          int Cin, int Cout, int stride, hipStream_t stream);
+                          int Cin, int Cout, int stride, hipStream_t stream, const ConvInIo* second = nullptr);   // second: 4 -> C form only
 int launch_pack_conv_weight(const float* w, bf16_t* out, int Cout, int Cin, int kh, int kw, hipStream_t stream);
 int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t stream);
 int launch_timestep_embedding(const int64_t* t, bf16_t* out, int batch, int dim, hipStream_t stream);
@@ -158,8 +179,11 @@ int launch_ddim_step(const float* x, const float* eps_c, const float* eps_u, flo
                      float* x_prev, float* pred_x0, int64_t n, hipStream_t stream);
 int launch_repeat_batch(const float* x, float* y, int64_t n_per, int reps, hipStream_t stream);
 int launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t stream);
-int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream);
-int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, const StepState* st, int64_t n,
+// first kernel of a replayed step: timestep / coefficients of step st->counter (+ the step's time-embedding rows when ts != null).
+// The counter itself is advanced by the step's LAST kernel (launch_ddim_step_state), so every workgroup here reads the same value.
+int launch_step_setup(StepState* st, int64_t* t_out, int batch, hipStream_t stream, const TembSel* ts = nullptr);
+int launch_temb_select(const TembSel& ts, int step, hipStream_t stream);          // the same copy with a host-side step index (eager loop)
+int launch_ddim_step_state(float* x, const float* eps_c, const float* eps_u, float cfg_scale, StepState* st, int64_t n,
                            hipStream_t stream);
 int launch_softmax_rows(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t stream);
 int launch_post_quant(const float* z, const bf16_t* w, const float* bias, float inv_scale, float* out, int batch, int C, int hw,

@@ -420,5 +420,9 @@ class MkdEngine:
     def eps_launches(self) -> int:
         return int(self.lib.mkd_eps_launches(self._ctx))
 
+    def step_launches(self) -> int:
+        """Kernel launches of one DDIM step inside ``sample`` (time embedding hoisted out of the loop)."""
+        return int(self.lib.mkd_step_launches(self._ctx))
+
     def device_bytes(self) -> int:
         return int(self.lib.mkd_device_bytes(self._ctx))

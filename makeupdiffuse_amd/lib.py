@@ -70,6 +70,7 @@ SIGNATURES = {
     'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.c_char_p]),
     'mkd_eps_flops': (C.c_double, [_P]),
     'mkd_eps_launches': (_I, [_P]),
+    'mkd_step_launches': (_I, [_P]),
     'mkd_device_bytes': (_L, [_P]),
     'mkd_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -248,13 +248,17 @@ def test_full_size_eps_vs_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize('dec_lanes,enc_lanes,overlap,helpers', [(0, 0, 1, 0), (0, 0, 0, 0), (2, 0, 1, 0), (2, 0, 1, 1), (4, 0, 1, 0), (2, 1, 1, 1), (4, 1, 1, 0)])
-def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overlap, helpers, monkeypatch):
+@pytest.mark.parametrize('dec_lanes,enc_lanes,overlap,helpers,group',
+                         [(0, 0, 1, 0, 0), (0, 0, 0, 0, 0), (2, 0, 1, 0, 0), (2, 0, 1, 1, 0), (4, 0, 1, 0, 0), (2, 1, 1, 1, 0), (4, 1, 1, 0, 0),
+                          (0, 0, 1, 0, 1), (0, 0, 0, 0, 1), (2, 0, 1, 0, 1), (2, 0, 1, 1, 1), (4, 0, 1, 0, 1)])
+def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overlap, helpers, group, monkeypatch):
     """Every multi-stream configuration (decoder helpers on the side stream, half-/quarter-batch decoder lanes, half-batch
-    encoder lanes): NaN-poison all buffers an evaluation produces, evaluate, and require the golden result, bit-identical
+    encoder lanes; the encoder phase as two chains on two streams or as one chain of grouped launches): NaN-poison all buffers an
+    evaluation produces, evaluate, and require the golden result, bit-identical
     across repetitions - a kernel that runs ahead of its producer would read NaN instead of the previous call's values."""
     monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes)); monkeypatch.setenv('MKD_ENC_LANES', str(enc_lanes))
     monkeypatch.setenv('MKD_DEC_OVERLAP', str(overlap)); monkeypatch.setenv('MKD_LANE_HELPERS', str(helpers))
+    monkeypatch.setenv('MKD_ENC_GROUP', str(group))
     g = np.load(os.path.join(GOLD, 'small_eps.npz'))
     ocfg = nets.NetConfig(**SMALL)
     sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
@@ -268,7 +272,7 @@ def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overl
         for i in range(4):
             eng.debug_poison()
             out = eng.eps(rep(G['x']), rep(G['t']))
-            check_eps(out, want, what=f'lanes dec={dec_lanes} enc={enc_lanes} overlap={overlap} rep {i}')
+            check_eps(out, want, what=f'lanes dec={dec_lanes} enc={enc_lanes} overlap={overlap} group={group} rep {i}')
             first = out if first is None else first
             assert torch.equal(out, first)
         # the captured-graph loop takes the same plan
@@ -366,4 +370,123 @@ def test_linear_graph_segments_equal_the_eager_loop(lanes, monkeypatch):
     d = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=False)
     e = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=True)
     assert torch.equal(d, e)
+    eng.close()
+
+
+def _small_engine():
+    g = np.load(os.path.join(GOLD, 'small_eps.npz'))
+    ocfg = nets.NetConfig(**SMALL)
+    sd = nets.init_state_dict(ocfg, seed=int(g['seed_weights']))
+    eng = MkdEngine(NetConfig(**SMALL))
+    eng.load_state_dict(sd)
+    return eng, {k: torch.from_numpy(g[k]) for k in g.files if k not in ('seed_weights', 'seed_vae')}
+
+
+@pytest.mark.parametrize('dec_lanes', [0, 2])
+def test_grouped_encoder_equals_the_two_chain_plan_bit_for_bit(dec_lanes, monkeypatch):
+    """MKD_ENC_GROUP: ControlNet and UNet encoder + middle block as ONE chain of grouped (2-problem) launches against two chains on
+    two streams (reference diffmk/makeup_diffuse.py:164-168, the two net calls of apply_model).  Same kernels, same tiles, same
+    order of operations per output element: the eps of a ragged batch, the 5-step latent (eager and graph replay) and the guided
+    loop are equal BIT FOR BIT, after NaN-poisoning; the grouped plan has one launch per encoder op pair."""
+    monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes))
+    res = {}
+    for group in (0, 1):
+        monkeypatch.setenv('MKD_ENC_GROUP', str(group))
+        eng, G = _small_engine()
+        rep = lambda t: torch.cat([t, t, t[:1]])
+        eng.prepare(rep(G['hint']), rep(G['ctx']))
+        eng.debug_poison()
+        e5 = eng.eps(rep(G['x']), rep(G['t']))
+        check_eps(e5, rep(G['eps']), what=f'MKD_ENC_GROUP={group}')
+        n_eps = eng.eps_launches()
+        sch = sampler.Schedule().make_ddim(5)
+        args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+        eng.prepare(G['hint'], G['ctx'])
+        eng.debug_poison()
+        a = eng.sample(G['x'], *args, use_graph=False)
+        eng.debug_poison()
+        b = eng.sample(G['x'], *args, use_graph=True)
+        assert torch.equal(a, b)
+        eng.prepare(torch.cat([G['hint'], G['hint']]), torch.cat([G['uctx'], G['ctx']]))
+        c = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=True)
+        eng.prepare(None, G['ctx'], latent_hw=(8, 8))            # c_concat None: nothing to group, same plan either way
+        d = eng.eps(G['x'], G['t'])
+        res[group] = (e5, a, c, d, n_eps)
+        eng.close()
+    for k in range(4):
+        assert torch.equal(res[0][k], res[1][k]), f'grouped plan differs from the two-chain plan (output {k})'
+    check_eps(res[1][1], G['x5'], rel=1.5e-2, cos=0.9999, what='5-step latent, grouped encoder')
+    print(f'launches per eps: two chains {res[0][4]}, grouped {res[1][4]}')
+    assert res[1][4] < res[0][4] - 20, 'the grouped plan must launch once per encoder op pair'
+
+
+def test_time_embedding_table_equals_the_per_step_chain_bit_for_bit(monkeypatch):
+    """mkd_sample computes the time embedding of ALL its steps once per call (timesteps are a host table, reference
+    diffmk/cddim.py:83-95) and a step only copies its row; MKD_TEMB_TABLE=0 runs the chain of mkd_eps in every step.  Latents are
+    equal bit for bit (eager, graph replay, guidance, a second call with other timesteps), and equal to stepping by hand with mkd_eps
+    + mkd_ddim_step; a step inside the loop launches less than a stand-alone mkd_eps."""
+    res = {}
+    for table in (0, 1):
+        monkeypatch.setenv('MKD_TEMB_TABLE', str(table))
+        eng, G = _small_engine()
+        sch = sampler.Schedule().make_ddim(5)
+        args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+        eng.prepare(G['hint'], G['ctx'])
+        a = eng.sample(G['x'], *args, use_graph=False)
+        b = eng.sample(G['x'], *args, use_graph=True)
+        sch7 = sampler.Schedule().make_ddim(7)
+        args7 = (sch7.ddim_timesteps, sch7.ddim_alphas, sch7.ddim_alphas_prev, sch7.ddim_sqrt_one_minus_alphas)
+        c = eng.sample(G['x'], *args7, use_graph=True)            # another step count: the table is re-built
+        b2 = eng.sample(G['x'], *args, use_graph=True)
+        e = eng.eps(G['x'], G['t'])                               # a stand-alone evaluation after a loop runs its own chain again
+        check_eps(e, G['eps'], what=f'eps after a sampling loop, MKD_TEMB_TABLE={table}')
+        # by hand: mkd_eps + mkd_ddim_step per step
+        x = G['x'].to(eng.device)
+        for i in range(4, -1, -1):
+            t = torch.full((x.shape[0],), int(sch.ddim_timesteps[i]), dtype=torch.int64)
+            ee = eng.eps(x, t)
+            x, _ = eng.ddim_step(x, ee, None, 1.0, float(sch.ddim_alphas[i]), float(sch.ddim_alphas_prev[i]), 0.0,
+                                 float(sch.ddim_sqrt_one_minus_alphas[i]))
+        assert torch.equal(a, b) and torch.equal(b, b2) and torch.equal(a, x.to(a.device))
+        eng.prepare(torch.cat([G['hint'], G['hint']]), torch.cat([G['uctx'], G['ctx']]))
+        d = eng.sample(G['x'], *args, cfg_scale=9.0, use_graph=True)
+        res[table] = (a, c, d, e, eng.step_launches(), eng.eps_launches())
+        eng.close()
+    for k in range(4):
+        assert torch.equal(res[0][k], res[1][k]), f'table-fed loop differs from the per-step chain (output {k})'
+    print(f'launches per step: chain {res[0][4]}, table {res[1][4]} (stand-alone eps {res[1][5]})')
+    assert res[1][4] <= res[0][4] - 6
+
+
+def test_split_setting_changed_after_prepare_is_loud_then_replanned(monkeypatch):
+    """A split conv1 -> GroupNorm pair is planned for a fixed slab count (op_gemm_then_gn; MKD_GN_SLAB_MINC=64 turns it on for a
+    256-channel test net).  Changing the split-K cap after mkd_prepare must not silently reduce the wrong number of slabs: the stale
+    plan's launch fails loudly, and the next mkd_prepare re-plans (the plan epoch moved) and agrees with the first result."""
+    from makeupdiffuse_amd import lib as mlib
+    monkeypatch.setenv('MKD_GN_SLAB_MINC', '64')
+    cfg = NetConfig(model_channels=256, channel_mult=(1,), attention_resolutions=(1,), num_heads=4, context_dim=64,
+                    hint_widths=(16, 16, 32, 32, 32, 32, 64))
+    eng = MkdEngine(cfg)
+    eng.init_random(0, norm_jitter=0.2)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 8, 8, generator=g); hint = torch.rand(2, 6, 64, 64, generator=g); ctx = torch.randn(2, 77, 64, generator=g)
+    t = torch.tensor([801, 41])
+    eng.prepare(hint, ctx)
+    ref = eng.eps(x, t)
+    assert torch.isfinite(ref).all()
+    try:
+        monkeypatch.setenv('MKD_SPLITK_CAP', '1')                 # read by mkd_ctx_create: process-wide cap, no GEMM splits K any more
+        other = MkdEngine(NetConfig(**SMALL))
+        with pytest.raises(mlib.MkdError, match='prepare again'):
+            eng.eps(x, t)
+        torch.cuda.synchronize()
+        eng.prepare(hint, ctx)                                    # re-planned: nothing is split, nothing deferred
+        check_eps(eng.eps(x, t), ref, rel=1e-2, what='re-planned without split-K')
+        other.close()
+    finally:
+        monkeypatch.setenv('MKD_SPLITK_CAP', '0')
+        last = MkdEngine(NetConfig(**SMALL))                      # (lifts the cap again)
+        last.close()
+    eng.prepare(hint, ctx)
+    assert torch.equal(eng.eps(x, t), ref)
     eng.close()
