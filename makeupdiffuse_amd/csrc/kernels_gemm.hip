@@ -738,6 +738,7 @@ static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, i
             if (s < 1) s = 1;
         }
     }
+    if (force_splitk <= 0 && g_splitk_cap > 0 && s > g_splitk_cap) s = g_splitk_cap;      // (the experiment cap covers heuristic plans too)
     if (s > nk) s = nk;
     GemmPlan g;
     g.cfg = cfg;

@@ -66,19 +66,32 @@ class BaseMakeUpDiffuse:
         self.first_stage_key, self.cond_stage_key, self.control_key = first_stage_key, cond_stage_key, control_key
         self.src_img_key = src_img_key if src_img_key else src_key
         self.ref_img_key = ref_img_key if ref_img_key else control_key
-        sch = DDIMSchedule(timesteps, linear_start, linear_end, beta_schedule)
-        self.schedule = sch
-        self.num_timesteps = sch.num_timesteps
-        for n in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
-                  'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod'):
-            setattr(self, n, getattr(sch, n))
+        self.linear_start, self.linear_end = linear_start, linear_end
         self.device = torch.device('cpu')
+        self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start, linear_end=linear_end)
         self.engine: Optional[MkdEngine] = None
         self._pending_sd: Optional[Dict[str, torch.Tensor]] = None
         self._bound = None
         self._cfg_cache = None
+        self._cat_cache = None
         self.cond_stage_model = None          # callable(list[str]) -> [B,77,768]; built on .cuda() when cond_stage_config is set
         self.training = False
+
+    _SCHEDULE_TABLES = ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
+                        'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod')
+
+    def register_schedule(self, given_betas=None, beta_schedule: str = 'linear', timesteps: int = 1000, linear_start: float = 1e-4,
+                          linear_end: float = 2e-2, cosine_s: float = 8e-3) -> None:
+        """UPSTREAM DDPM.register_schedule as the reference calls it (diffmk/makeups.py:40-42, ``update_schedule``): (re)builds
+        the beta / alphas_cumprod tables for ``timesteps`` steps.  Samplers built afterwards see the new ``num_timesteps``."""
+        if given_betas is not None:
+            raise NotImplementedError('given_betas (the reference passes None, diffmk/makeups.py:41)')
+        sch = DDIMSchedule(int(timesteps), linear_start, linear_end, beta_schedule)
+        self.schedule = sch
+        self.num_timesteps = sch.num_timesteps
+        self.linear_start, self.linear_end = linear_start, linear_end
+        for n in self._SCHEDULE_TABLES:
+            setattr(self, n, getattr(sch, n).to(self.device))
 
     # ---- nn.Module-ish surface used by runs/test.py --------------------------------------------------------
     def cpu(self):
@@ -180,10 +193,26 @@ class BaseMakeUpDiffuse:
             self._bound = _Held((hint, ctx), extra)
         return eng
 
+    def _bind_cond(self, cond: dict, latent_hw) -> MkdEngine:
+        """cat(c_crossattn, 1) / cat(c_concat, 1) of a cond dict (reference diffmk/makeup_diffuse.py:159,165) bound to the engine.
+        A list with several entries is concatenated ONCE per distinct set of entries: the key holds the list ELEMENTS (a fresh
+        torch.cat result would never match itself and the hint block / K-V caches would be rebuilt every DDIM step)."""
+        xs = list(cond['c_crossattn'])
+        hs = None if cond.get('c_concat') is None else list(cond['c_concat'])
+        if len(xs) == 1 and (hs is None or len(hs) == 1):
+            return self._bind(None if hs is None else hs[0], xs[0], latent_hw)
+        parts = xs + (hs or [])
+        shape = (len(xs), -1 if hs is None else len(hs))
+        if self._cat_cache is None or not self._cat_cache[0].matches(parts, shape):
+            self._cat_cache = (_Held(parts, shape), torch.cat(xs, 1) if len(xs) > 1 else xs[0],
+                               None if hs is None else (torch.cat(hs, 1) if len(hs) > 1 else hs[0]))
+        return self._bind(self._cat_cache[2], self._cat_cache[1], latent_hw)
+
     def reset_conditioning_cache(self) -> None:
         """Drop the prepared-conditioning and CFG-merge caches (and the tensors they hold)."""
         self._bound = None
         self._cfg_cache = None
+        self._cat_cache = None
 
     def cfg_conditioning(self, uncond: dict, cond: dict) -> dict:
         """[uncond; cond] batching (cddim.py:18-38), cached per (uncond, cond) pair so that a step-by-step
@@ -214,11 +243,7 @@ class BaseMakeUpDiffuse:
     @torch.no_grad()
     def apply_model(self, x_noisy: torch.Tensor, t: torch.Tensor, cond: dict, return_all: bool = False, *args, **kwargs):
         assert isinstance(cond, dict)
-        cond_txt = torch.cat(cond['c_crossattn'], 1) if len(cond['c_crossattn']) > 1 else cond['c_crossattn'][0]
-        hint = None
-        if cond.get('c_concat') is not None:
-            hint = torch.cat(cond['c_concat'], 1) if len(cond['c_concat']) > 1 else cond['c_concat'][0]
-        eng = self._bind(hint, cond_txt, x_noisy.shape[2:])
+        eng = self._bind_cond(cond, x_noisy.shape[2:])
         eps = eng.eps(x_noisy, t)
         if not return_all:
             return eps
@@ -237,11 +262,7 @@ class BaseMakeUpDiffuse:
                          unconditional_guidance_scale=1.0, unconditional_conditioning=None):
         cfg_on = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
         c = self.cfg_conditioning(unconditional_conditioning, cond) if cfg_on else cond
-        cond_txt = torch.cat(c['c_crossattn'], 1) if len(c['c_crossattn']) > 1 else c['c_crossattn'][0]
-        hint = None
-        if c.get('c_concat') is not None:
-            hint = torch.cat(c['c_concat'], 1) if len(c['c_concat']) > 1 else c['c_concat'][0]
-        eng = self._bind(hint, cond_txt, x_latent.shape[2:])
+        eng = self._bind_cond(c, x_latent.shape[2:])
         return eng.sample(x_latent, [int(v) for v in timesteps], [float(v) for v in alphas], [float(v) for v in alphas_prev],
                           [float(v) for v in sqrt_one_minus_alphas],
                           cfg_scale=float(unconditional_guidance_scale) if cfg_on else 1.0)

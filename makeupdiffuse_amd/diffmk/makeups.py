@@ -31,11 +31,15 @@ class BaseModel(BaseMakeUpDiffuse):
         self.t0, self.inv_steps, self.iter_finetune = t0, inv_steps, iter_finetune
         self.ddim_sampler: Optional[MKDDIMSampler] = None
 
+    def update_schedule(self) -> None:
+        """:40-42: re-registers the LINEAR beta schedule with ``timesteps = t0`` (same linear_start / linear_end): the DDIM
+        inversion and its fine-tune run on a t0-step DDPM chain."""
+        self.register_schedule(given_betas=None, beta_schedule='linear', timesteps=self.t0, linear_start=self.linear_start,
+                               linear_end=self.linear_end, cosine_s=8e-3)
+
     def on_fit_start(self) -> None:
-        """:44-47.  ``update_schedule`` re-registers the linear schedule with ``timesteps = t0``; only t0 equal to the
-        configured number of timesteps is supported (anything else would need a different alphas_cumprod table)."""
-        if self.t0 != self.num_timesteps:
-            raise NotImplementedError(f't0 = {self.t0} differs from the configured {self.num_timesteps} timesteps')
+        """:44-47."""
+        self.update_schedule()
         self.ddim_sampler = MKDDIMSampler(self)
         self.ddim_sampler.make_schedule(ddim_num_steps=self.iter_finetune)
 

@@ -22,11 +22,14 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun env; initialises the default group when WORLD_SIZE > 1."""
+    """(rank, world, local_rank) from the torchrun env; initialises the default group when WORLD_SIZE > 1 - and also for a
+    world of ONE when a backend is asked for explicitly (argument or MKD_DIST_BACKEND) with WORLD_SIZE set: the same RCCL
+    init / all-gather / all-reduce / barrier code path, runnable on a one-GPU box."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    explicit = (backend or os.environ.get('MKD_DIST_BACKEND')) and 'WORLD_SIZE' in os.environ
+    if (world > 1 or explicit) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -76,11 +79,11 @@ def spawn_ranks(argv, world: int, env_extra: Optional[dict] = None, timeout: Opt
 def gather_shards(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """All-gather per-rank batch shards (possibly ragged by one) into the full [n_total, ...] tensor, in
     global sample order, on every rank.  Single collective: shards are padded to the largest shard."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         if local.shape[0] != n_total:
             raise ValueError('single-process gather: shard is not the whole batch')
         return local
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)          # (a group of one still runs the collective: same code path as N ranks)
     rank = dist.get_rank(group)
     lo, hi = shard_range(n_total, rank, world)
     if local.shape[0] != hi - lo:

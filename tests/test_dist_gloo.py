@@ -108,3 +108,43 @@ def test_bench_self_launch_is_decided_before_any_gpu_call():
     main = src[src.index('def main():'):]
     assert main.index('spawn_ranks') < main.index('init_from_env') < main.index('torch.cuda.is_available()')
     assert 'os.exec' not in src and 'execv' not in src
+
+
+def test_group_of_one_runs_the_real_collectives(tmp_path):
+    """WORLD_SIZE=1 with an explicit backend (MKD_DIST_BACKEND): init_from_env still builds the process group and gather_shards /
+    max_over_ranks / barrier go through torch.distributed - the path the -m gpu suite repeats with backend nccl (RCCL) on the card."""
+    import subprocess
+    import sys
+    from makeupdiffuse_amd import dist as mdist
+    child = tmp_path / 'one.py'
+    child.write_text(
+        'import json, sys\n'
+        f'sys.path.insert(0, {ROOT!r})\n'
+        'import torch\n'
+        'from makeupdiffuse_amd import dist as mdist\n'
+        'rank, world, local = mdist.init_from_env()\n'
+        'x = torch.arange(6, dtype=torch.float32).reshape(3, 2)\n'
+        'g = mdist.gather_shards(x, 3)\n'
+        'mdist.barrier()\n'
+        "print(json.dumps({'init': torch.distributed.is_initialized(), 'backend': torch.distributed.get_backend(), 'world': world,\n"
+        "                  'same_storage': g.data_ptr() == x.data_ptr(), 'equal': bool(torch.equal(g, x)), 'max': mdist.max_over_ranks(2.5)}), flush=True)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(mdist.free_port()), MKD_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, str(child)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out == {'init': True, 'backend': 'gloo', 'world': 1, 'same_storage': False, 'equal': True, 'max': 2.5}
+    # without an explicit backend a single process stays group-free (no rendezvous, the shard IS the batch)
+    env.pop('MKD_DIST_BACKEND')
+    child2 = tmp_path / 'none.py'
+    child2.write_text(
+        'import sys\n'
+        f'sys.path.insert(0, {ROOT!r})\n'
+        'import torch\n'
+        'from makeupdiffuse_amd import dist as mdist\n'
+        'mdist.init_from_env()\n'
+        'x = torch.zeros(2, 1)\n'
+        'assert not torch.distributed.is_initialized() and mdist.gather_shards(x, 2) is x\n')
+    r = subprocess.run([sys.executable, str(child2)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]

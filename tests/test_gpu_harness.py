@@ -99,3 +99,37 @@ def test_bench_self_launches_two_ranks_on_one_card_in_rehearsal_mode():
     assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == 'gloo' and out['rehearsal_single_device'] is True
     assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
     assert out['roofline']['frac'] > 0 and len(out['devices']) == 1
+
+
+def test_rccl_group_of_one_on_the_card():
+    """SURVEY.md §8e on the hardware that IS here: a fresh process with WORLD_SIZE=1 and MKD_DIST_BACKEND=nccl initialises the RCCL
+    process group (dist.init_from_env), runs gather_shards / max_over_ranks / barrier on DEVICE tensors - the real collectives, not
+    the single-process shortcut - and a 2-step `bench.py --gpus 1` under the same environment reports backend nccl, one rank.
+    (N > 1 over xGMI stays unmeasured: no multi-GPU node is reachable from here.)"""
+    import json
+    from makeupdiffuse_amd import dist as mdist
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(mdist.free_port()), MKD_DIST_BACKEND='nccl',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    code = (
+        "import torch, torch.distributed as d\n"
+        "from makeupdiffuse_amd import dist as m\n"
+        "r, w, l = m.init_from_env()\n"
+        "assert (r, w, l) == (0, 1, 0) and d.is_initialized() and d.get_backend() == 'nccl' and d.get_world_size() == 1\n"
+        "x = torch.arange(24, dtype=torch.float32, device='cuda:0').reshape(3, 2, 4)\n"
+        "g = m.gather_shards(x, 3)\n"
+        "assert g.is_cuda and g.data_ptr() != x.data_ptr() and torch.equal(g, x)\n"
+        "assert m.max_over_ranks(1.25, torch.device('cuda:0')) == 1.25\n"
+        "m.barrier(); torch.cuda.synchronize(); d.destroy_process_group()\n"
+        "print('RCCL_OK', torch.cuda.get_device_name(0))\n")
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    env['MASTER_PORT'] = str(mdist.free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0', '--ddim-steps', '2',
+                        '--batch', '2', '--no-cpu-baseline'], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['backend'] == 'nccl' and out['ranks_seen'] == 1 and out['n_gpus'] == 1 and out['rehearsal_single_device'] is False
+    assert out['value'] > 0

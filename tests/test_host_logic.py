@@ -311,3 +311,95 @@ def test_hot_kernels_use_no_scratch(tmp_path):
         spills = re.findall(r'^\s+\.vgpr_spill_count:\s+(\d+)', txt, flags=re.M)
         assert sizes and all(int(v) == 0 for v in sizes), (src, sizes)
         assert all(int(v) == 0 for v in spills), (src, spills)
+
+
+# ---- round 3: the earlier variant's batch contract, update_schedule, multi-entry cond lists -----------------------------------
+def _ctrl_params():
+    return dict(SMALL, hint_channels=6, num_res_blocks=2, in_channels=4, use_spatial_transformer=True, legacy=False)
+
+
+def test_makeup_double_control_model_takes_channels_last_batches():
+    """reference diffmk/makeup_controlnet.py:137-167: control images arrive [b, h, w, c] under control_src_key / control_key, are
+    rearranged 'b h w c -> b c h w', and the cond dict is the one the newer class builds from CHW src_img / ref_img
+    (diffmk/makeup_diffuse.py:42-57): 6-channel hint, SOURCE FIRST, c_crossattn = [txt]."""
+    from diffmk.makeup_controlnet import BaseModel, MakeupDoubleControlModel
+    from diffmk.makeup_diffuse import BaseMakeUpDiffuse
+    ctrl = _ctrl_params()
+    g = torch.Generator().manual_seed(2)
+    src = torch.rand(3, 16, 24, 3, generator=g); ref = torch.rand(3, 16, 24, 3, generator=g); txt = torch.randn(3, 77, 64, generator=g)
+    for cls in (MakeupDoubleControlModel, BaseModel):
+        m = cls('source', control_stage_config={'params': ctrl}, unet_config={'params': dict(ctrl, out_channels=4)}, control_key='hint')
+        assert m.control_src_key == 'source' and m.control_key == 'hint'
+        z, c = m.get_input({'source': src, 'hint': ref, 'txt_emb': txt, 'jpg': torch.zeros(3, 16, 24, 3)}, 'jpg')
+        hint = c['c_concat'][0]
+        assert z is None and sorted(c) == ['c_concat', 'c_crossattn'] and len(c['c_concat']) == 1 and len(c['c_crossattn']) == 1
+        assert hint.shape == (3, 6, 16, 24) and hint.dtype == torch.float32 and hint.is_contiguous()
+        assert torch.equal(hint[:, :3], src.permute(0, 3, 1, 2)) and torch.equal(hint[:, 3:], ref.permute(0, 3, 1, 2))      # :167 (src, ref)
+        assert torch.equal(c['c_crossattn'][0], txt)
+        # the newer class on the SAME images delivered channels-first gives the same conditioning
+        n = BaseMakeUpDiffuse(control_stage_config={'params': ctrl}, unet_config={'params': dict(ctrl, out_channels=4)})
+        _, c2 = n.get_input({'src_img': src.permute(0, 3, 1, 2), 'ref_img': ref.permute(0, 3, 1, 2), 'txt_emb': txt}, 'jpg')
+        assert torch.equal(c2['c_concat'][0], hint) and torch.equal(c2['c_crossattn'][0], c['c_crossattn'][0])
+        _, c3 = m.get_input({'source': src, 'hint': ref, 'txt_emb': txt}, 'jpg', bs=2)                                       # :148-156 bs
+        assert c3['c_concat'][0].shape[0] == 2 and c3['c_crossattn'][0].shape[0] == 2
+        with pytest.raises(ValueError):
+            m.get_input({'source': src[0], 'hint': ref, 'txt_emb': txt}, 'jpg')
+    d = MakeupDoubleControlModel('source', control_stage_config={'params': ctrl}, unet_config={'params': dict(ctrl, out_channels=4)})
+    assert d.get_origin_img_input({'k': src}, 'k').shape == (3, 3, 16, 24)                    # :106-114 rearranges by default
+    assert d.get_origin_img_input({'k': src}, 'k', need_rearrange=False).shape == (3, 16, 24, 3)
+
+
+def test_update_schedule_reregisters_the_linear_schedule_with_t0_steps():
+    """reference diffmk/makeups.py:40-47: on_fit_start -> update_schedule -> register_schedule(beta_schedule='linear',
+    timesteps=t0, same linear_start / linear_end) -> MKDDIMSampler.make_schedule(ddim_num_steps=iter_finetune).  Known answers
+    from the closed form (SURVEY.md App. B formulae at 600 steps): betas = linspace(sqrt(.00085), sqrt(.012), 600)^2."""
+    from diffmk.makeups import BaseModel
+    ctrl = _ctrl_params()
+    m = BaseModel(control_stage_config={'params': ctrl}, unet_config={'params': dict(ctrl, out_channels=4)}, t0=600, iter_finetune=40)
+    assert m.num_timesteps == 1000 and m.alphas_cumprod.shape[0] == 1000
+    m.on_fit_start()
+    assert m.num_timesteps == 600 and m.alphas_cumprod.shape[0] == 600 and m.ddim_sampler.ddpm_num_timesteps == 600
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 600, dtype=np.float64) ** 2
+    ac = np.cumprod(1.0 - betas)
+    assert abs(float(m.betas[0]) - 0.00085) < 1e-9 and abs(float(m.betas[-1]) - 0.012) < 1e-8
+    assert np.allclose(m.alphas_cumprod.numpy(), ac.astype(np.float32), rtol=0, atol=1e-7)
+    assert abs(float(m.alphas_cumprod[0]) - 0.99915) < 1e-6 and abs(float(m.alphas_cumprod[-1]) - ac[-1]) < 1e-7
+    assert ac[-1] > 0.0046600985 * 3                         # a 600-step chain ends far less noisy than the 1000-step one (App. B value)
+    ts = m.ddim_sampler.ddim_timesteps
+    assert ts.shape[0] == 40 and int(ts[0]) == 1 and int(ts[1]) == 16 and int(ts[-1]) == 586      # arange(0, 600, 600 // 40) + 1
+    assert np.allclose(m.ddim_sampler.ddim_alphas.numpy(), ac[ts].astype(np.float32), atol=1e-7)
+    assert abs(float(m.ddim_sampler.ddim_alphas_prev[0]) - ac[0]) < 1e-7 and abs(float(m.ddim_sampler.ddim_alphas_prev[1]) - ac[1]) < 1e-7
+    assert float(m.ddim_sampler.ddim_sigmas.abs().max()) == 0.0
+    m.t0 = 1000
+    m.update_schedule()
+    assert m.num_timesteps == 1000 and torch.equal(m.alphas_cumprod, DDIMSchedule().alphas_cumprod)
+    with pytest.raises(NotImplementedError):
+        m.register_schedule(given_betas=betas)
+
+
+def test_multi_entry_cond_lists_are_concatenated_once_per_distinct_set():
+    """apply_model cats c_crossattn / c_concat lists (reference diffmk/makeup_diffuse.py:159,165); a cache keyed on the
+    CAT RESULT never matches, so every DDIM step would re-run mkd_prepare.  The key holds the list elements."""
+    m = create_model(os.path.join(ROOT, 'diffmodels', 'test_diffusion_makeup.yaml'))
+    eng = _RecordingEngine()
+    m._require_engine = lambda: eng
+    x, t = torch.zeros(1, 4, 8, 8), torch.zeros(1, dtype=torch.long)
+    a, b = torch.full((1, 40, 768), 1.0), torch.full((1, 37, 768), 2.0)
+    s, r = torch.full((1, 3, 64, 64), 0.25), torch.full((1, 3, 64, 64), 0.75)
+    cond = {'c_crossattn': [a, b], 'c_concat': [s, r]}
+    for _ in range(3):
+        m.apply_model(x, t, cond)
+    assert len(eng.prepared) == 1
+    m.apply_model(x, t, {'c_crossattn': [a, b], 'c_concat': [s, r]})          # new lists, same elements
+    assert len(eng.prepared) == 1
+    m.apply_model(x, t, {'c_crossattn': [a, b], 'c_concat': [r, s]})          # another order is another hint
+    assert len(eng.prepared) == 2
+    b.add_(1.0)
+    m.apply_model(x, t, {'c_crossattn': [a, b], 'c_concat': [r, s]})
+    assert len(eng.prepared) == 3
+    import weakref
+    ref = weakref.ref(s)
+    del s, cond
+    m.reset_conditioning_cache()
+    m.apply_model(x, t, {'c_crossattn': [a], 'c_concat': [r]})
+    assert len(eng.prepared) == 4
