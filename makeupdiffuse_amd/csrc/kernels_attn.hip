@@ -18,17 +18,18 @@ namespace {
 
 // keys per tile: 64 (self-attention streams tiles with an online softmax) or 96 (KT template parameter): the 77 context keys of
 // the cross-attention then fit ONE tile - no second, 80 %-masked tile, no rescale of O, one barrier pair instead of two.
-// MKD_ATTN_TAIL=1 sends the last 8 / 16 channels of dh = 40 / 80 through one 16-deep MFMA (40 padded to 48, not 64).  In the
-// 8-wave build (accumulators in VGPRs) a 16x16x16 result feeding a 16x16x32 SrcC, or the reverse, was read too early
-// (sporadically wrong scores; the 4-wave build keeps them in AGPRs and is right); with 32 explicit wait states it is correct
-// but only 3 % faster at 4096 tokens and slower at 1024 -> OFF.
+// MKD_ATTN_TAIL (compile time): the last 8 / 16 channels of dh = 40 / 80 go through one 16-deep MFMA (40 padded to 48, not 64), with
+// an accumulator of its own (see the hazard note at the MFMA).  1 (default): in the one-tile cross-attention kernel (KT = 96) only,
+// 2: everywhere, 0: nowhere.  Measured at batch 8 (tools/exp_r3_attn_tail.sh, us per launch without / with): cross-attention
+// 4096 x 77 dh 40 24.6 / 22.1, 1024 x 77 8.2 / 7.3, 256 x 77 dh 80 5.7 / 5.5; self-attention 4096^2 dh 40 448 / 462, 1024^2 32.0 /
+// 33.2 (the streaming kernel is VALU-bound and the join costs 16 adds per tile), dh 80 45.2 / 45.0.
 #ifndef MKD_ATTN_TAIL
-#define MKD_ATTN_TAIL 0
+#define MKD_ATTN_TAIL 1
 #endif
 
 template <int DH, int KT>
 struct AttnCfg {
-    static constexpr int TAIL = (MKD_ATTN_TAIL && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
+    static constexpr int TAIL = ((MKD_ATTN_TAIL == 2 || (MKD_ATTN_TAIL == 1 && KT == 96)) && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
     static constexpr int KS = TAIL ? DH / 32 : (DH + 31) / 32;          // 32-deep k-steps of QK^T
     static constexpr int DHP = 32 * KS + 16 * TAIL;      // QK^T contraction depth, zero padded (40 -> 48, not 64)
     static constexpr int DVP = (DH + 15) / 16 * 16;      // output rows of O^T (padded)
@@ -154,18 +155,23 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         for (int mf = 0; mf < KB; ++mf) {
             st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             const char* krow = ks + (16 * mf + qc) * C::KROW;
-            if (C::TAIL) {                   // the 16-deep step first: the 32-deep steps then accumulate on its result
+            // The 16-deep tail step keeps an accumulator of its OWN and joins the 32-deep chain with a VALU add.  Chaining it
+            // through SrcC is the hazard that made this variant sporadically wrong in the 8-wave build: an XDL result read as
+            // SrcC of a DIFFERENT opcode with a different vDst gets no forwarding and needs the producer's full pass count in
+            // wait states (CDNA3 ISA 4.5, table "XDL write VGPR -> XDL read SrcC, overlapped, different vDst": passes + 1); the
+            // compiler emitted none between v_mfma_f32_16x16x16_bf16 and v_mfma_f32_16x16x32_bf16.  XDL write -> VALU read is
+            // the dependency every GEMM epilogue has, and its wait states are inserted correctly.
+            f32x4 tl = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (C::TAIL) {
                 const bf16x4v kt = *(const bf16x4v*)(krow + (32 * C::KS + 4 * g) * 2);
-                st[mf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kt), __builtin_bit_cast(s16x4, qt), st[mf], 0, 0, 0);
-                // A 16x16x16 result feeding a 16x16x32 MFMA's SrcC (VGPR form, different vDst) was observed to be read too early
-                // in the 8-wave build (sporadically wrong scores): keep 32 wait states between the two, tied to the register.
-                if (C::KS) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(st[mf]));
+                tl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kt), __builtin_bit_cast(s16x4, qt), tl, 0, 0, 0);
             }
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) {
                 const bf16x8 kf = *(const bf16x8*)(krow + (32 * s + 8 * g) * 2);
                 st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[mf], 0, 0, 0);
             }
+            if (C::TAIL) st[mf] += tl;
         }
         // lane holds RAW scores of query qc for keys key0 + 16*mf + 4*g + r.  The softmax runs in the log2 domain with the
         // scale folded into one FMA per score: p = exp2(s*c - m), m = running max of s*c (c = scale*log2(e) > 0).
