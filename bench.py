@@ -50,25 +50,44 @@ PEAK_HBM_GBS = 8000.0
 MFMA_PREFIXES = ('gemm_', 'attention')
 
 
+def _csrc_sha16():
+    import hashlib
+    src = b''.join(open(os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc', f), 'rb').read()
+                   for f in ('engine.hip', 'kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_misc.hip', 'gemm_tuned.inc'))
+    return hashlib.sha256(src).hexdigest()[:16]
+
+
 def pmc_traffic_bytes_per_launch(kernel_fn):
-    """HBM-side bytes per launch of `kernel_fn` from the committed rocprofv3 --pmc summaries (profiles/, separate passes for
+    """HBM-side bytes per launch of `kernel_fn` from the COMMITTED rocprofv3 --pmc summaries (profiles/, separate passes for
     FETCH_SIZE and WRITE_SIZE): KB -> bytes, FETCH doubled for wide streaming reads on gfx950 (MI355X_MICROARCH.md §HBM).
-    None when the summaries are absent.  (PMC cannot be collected from inside this process.)"""
+    (PMC cannot be collected from inside this process, so this number does not move between runs of one build: the second return
+    value says which files / commit it comes from and whether the kernel sources are still the ones that were profiled.)"""
     import csv
-    tot = {}
-    for name, mult in (('r2_pmc_fetch_size_kb.csv', 2.0), ('r2_pmc_write_size_kb.csv', 1.0)):
-        path = os.path.join(ROOT, 'profiles', name)
-        if not os.path.exists(path):
-            return None
-        n = 0; b = 0.0
-        for r in csv.DictReader(open(path)):
-            if r['kernel'].startswith(kernel_fn):
-                col = [c for c in r if c.startswith('avg_') and c != 'avg_us'][0]
-                n += int(r['dispatches']); b += int(r['dispatches']) * float(r[col]) * 1024.0 * mult
-        if n == 0:
-            return None
-        tot[name] = b / n
-    return sum(tot.values())
+    for rnd in ('r3', 'r2'):
+        tot = {}
+        for name, mult in ((f'{rnd}_pmc_fetch_size_kb.csv', 2.0), (f'{rnd}_pmc_write_size_kb.csv', 1.0)):
+            path = os.path.join(ROOT, 'profiles', name)
+            if not os.path.exists(path):
+                tot = None
+                break
+            n = 0; b = 0.0
+            for r in csv.DictReader(open(path)):
+                if r['kernel'].startswith(kernel_fn):
+                    col = [c for c in r if c.startswith('avg_') and c != 'avg_us'][0]
+                    n += int(r['dispatches']); b += int(r['dispatches']) * float(r[col]) * 1024.0 * mult
+            if n == 0:
+                tot = None
+                break
+            tot[name] = b / n
+        if tot is None:
+            continue
+        src = {'files': sorted('profiles/' + k for k in tot), 'collected_live': False}
+        prov = os.path.join(ROOT, 'profiles', f'{rnd}_provenance.json')
+        if os.path.exists(prov):
+            pv = json.load(open(prov))
+            src.update(commit=pv.get('commit'), utc=pv.get('utc'), same_kernel_sources_as_this_run=pv.get('csrc_sha256_16') == _csrc_sha16())
+        return sum(tot.values()), src
+    return None, None
 
 
 def synth_inputs(lo, hi, res, ctx_dim, device):
@@ -261,13 +280,35 @@ def main():
         dom = max(agg, key=lambda f: agg[f]['ms'])
         d = agg[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes_per_launch(dom)
+        b2b_ms = sum(v['ms_b2b'] for k, v in prof.items() if fam[dom](k))
         roofline = {'bound': 'mfma', 'kernel': dom + ' (all tile configurations, one eps evaluation)', 'achieved': ach,
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                    'traffic': pmc_traffic_bytes_per_launch(dom),
+                    'traffic': traffic, 'traffic_source': traffic_src,
                     'launches_per_eval': d['launches'], 'avg_launch_us': 1e3 * d['ms'] / max(1, d['launches']),
                     'flops_per_launch': d['flops'] / max(1, d['launches']),
                     'share_of_eval_time': d['ms'] / tot_ms if tot_ms else None,
+                    # the same launches replayed back to back between ONE event pair: no 3-5 us of event overhead per launch
+                    'avg_launch_us_back_to_back': 1e3 * b2b_ms / max(1, d['launches']),
+                    'achieved_back_to_back': d['flops'] / (b2b_ms * 1e-3) / 1e12 if b2b_ms > 0 else None,
                     'other_kernels_tflops': {f: (v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0) for f, v in agg.items() if f != dom}}
+        # the dominant HBM-bound class (north_star: "HBM GB/s AND MFMA utilisation against peak"): algorithmic bytes from the plan
+        hbm_fn = {'groupnorm': 'gn_fused_kernel / gn_slab_kernel', 'layernorm': 'layernorm_kernel'}
+        hb = {k: v for k, v in prof.items() if k in hbm_fn and v['launches'] > 0 and v['ms'] > 0}
+        roofline_hbm = None
+        if hb:
+            hk = max(hb, key=lambda k: hb[k]['ms'])
+            hv = hb[hk]
+            gbs = hv['bytes'] / (hv['ms'] * 1e-3) / 1e9
+            gbs_b2b = hv['bytes'] / (hv['ms_b2b'] * 1e-3) / 1e9 if hv['ms_b2b'] > 0 else None
+            h_traffic, h_src = pmc_traffic_bytes_per_launch(hbm_fn[hk].split(' ')[0])
+            roofline_hbm = {'bound': 'hbm', 'kernel': f'{hbm_fn[hk]} ({hk} class, one eps evaluation)', 'achieved': gbs, 'peak': PEAK_HBM_GBS,
+                            'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'traffic': h_traffic, 'traffic_source': h_src,
+                            'launches_per_eval': hv['launches'], 'avg_launch_us': 1e3 * hv['ms'] / hv['launches'],
+                            'bytes_per_launch': hv['bytes'] / hv['launches'], 'share_of_eval_time': hv['ms'] / tot_ms if tot_ms else None,
+                            'avg_launch_us_back_to_back': 1e3 * hv['ms_b2b'] / hv['launches'],
+                            'achieved_back_to_back': gbs_b2b, 'frac_back_to_back': gbs_b2b / PEAK_HBM_GBS if gbs_b2b else None,
+                            'other_classes_gbs': {k: v['bytes'] / (v['ms'] * 1e-3) / 1e9 for k, v in hb.items() if k != hk}}
         loop_tflops = eps_flops * evals_per_step / (loop_ms * 1e-3) / 1e12
         result = {
             'metric': 'makeup-transfer images/sec @256x256, 50 DDIM steps' if args.res == 256 and args.ddim_steps == 50
@@ -287,6 +328,7 @@ def main():
             'rehearsal_single_device': os.environ.get('MKD_BENCH_SINGLE_DEVICE') == '1',
             'devices': sorted(set(dev_names)),
             'roofline': roofline,
+            'roofline_hbm': roofline_hbm,
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
                      'launches_per_eval': eng.step_launches(), 'launches_per_standalone_eps': eng.eps_launches(),

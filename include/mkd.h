@@ -173,6 +173,12 @@ int mkd_kind_count(void);
 const char* mkd_kind_name(int kind);
 int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream,
                     double* ms_per_kind, double* flops_per_kind, int* launches_per_kind, const char* csv_path);
+/* The same, plus per class: the ALGORITHMIC HBM bytes of the memory-bound launches (GroupNorm / LayerNorm: one read + one write of
+ * the tensor; slab-fed GroupNorm: its fp32 slabs in, bf16 out) and the class's launches replayed back to back between ONE event pair
+ * (per-launch time without the event overhead of the per-launch pass).  Either array may be NULL. */
+int mkd_eps_profile2(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream,
+                     double* ms_per_kind, double* flops_per_kind, int* launches_per_kind, double* bytes_per_kind,
+                     double* ms_back_to_back_per_kind, const char* csv_path);
 /* Bytes of device memory held by the context (weights + workspace). */
 int64_t mkd_device_bytes(const mkd_ctx* ctx);
 

@@ -108,6 +108,7 @@ struct Op {
     bool temb = false;      // part of the time-embedding chain (left out of the step when mkd_sample runs from its table)
     int kind = 0;
     double flops = 0;
+    double bytes = 0;       // algorithmic HBM bytes of the memory-bound ops (norms, split-K reduce inside slab-fed GroupNorm): what MUST move
     int launches = 0;
     std::string label;
     int sid = 0;            // 0: caller's stream, 1..3: side streams, HELPER_BASE + k: helper work on side stream k
@@ -705,6 +706,7 @@ struct mkd_ctx {
         }, 1, 0.0, K_GROUPNORM, "slab B=" + std::to_string(nb) + " HW=" + std::to_string(hw) + " C=" + std::to_string(a.N) + " splitk=" + std::to_string(sk));
         OpDesc& d = last_desc(); d.type = D_GN_SLAB; d.sid = sid; d.gemm = a; d.sk = sk; d.raw = raw ? 1 : 0; d.nio = NormIo{nullptr, y, gamma, beta};
         d.eps = eps; d.silu = silu; d.ld_out = ld_y; d.nb = nb; d.hw = hw;
+        if (!dry) cur_plan->back().bytes = (double)a.M * a.N * (sizeof(float) * sk + sizeof(bf16_t) * (raw ? 2 : 1));      // sk fp32 slabs in, bf16 out
         return true;
     }
     void op_gn(const Tensor& in, const float* gamma, const float* beta, float eps, int silu, bf16_t* out, int ld_out) {
@@ -725,11 +727,13 @@ struct mkd_ctx {
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
         OpDesc& d = last_desc(); d.type = D_GN; d.sid = sid; d.nio = NormIo{in.p, out, gamma, beta}; d.eps = eps; d.silu = silu;
         d.ld_in = in.ld; d.ld_out = ld_out; d.nb = in.B; d.hw = in.H * in.W; d.C = in.C;
+        if (!dry) cur_plan->back().bytes = 2.0 * sizeof(bf16_t) * in.B * in.H * in.W * (double)in.C;          // one read + one write of the tensor
     }
     void op_ln(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int d, int ldx = 0) {
         push(*cur_plan, [=](hipStream_t st) { return launch_layernorm(x, gamma, beta, 1e-5f, y, rows, d, st, ldx); }, 1, 0.0, K_LAYERNORM,
              "rows=" + std::to_string(rows) + " d=" + std::to_string(d));
         OpDesc& ds = last_desc(); ds.type = D_LN; ds.nio = NormIo{x, y, gamma, beta}; ds.eps = 1e-5f; ds.nb = rows; ds.C = d; ds.ld_in = ldx;
+        if (!dry) cur_plan->back().bytes = 2.0 * sizeof(bf16_t) * rows * (double)d;
     }
     void op_attn(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, bf16_t* o, int ldo,
                  int B_, int Tq, int Tk, int heads, int dh) {
@@ -1412,7 +1416,7 @@ struct mkd_ctx {
             default: return false;
         }
         Op g;
-        g.fn = std::move(fn); g.kind = a.kind; g.flops = a.flops + b.flops; g.launches = a.launches; g.label = a.label + " x2"; g.sid = 0; g.cap_sid = -1;
+        g.fn = std::move(fn); g.kind = a.kind; g.flops = a.flops + b.flops; g.bytes = a.bytes + b.bytes; g.launches = a.launches; g.label = a.label + " x2"; g.sid = 0; g.cap_sid = -1;
         g.temb = a.temb;
         *out = std::move(g);
         return true;
@@ -1545,8 +1549,11 @@ struct mkd_ctx {
     }
 
     // one eps with a hipEvent pair around every plan op: per-kernel-class device time (bench roofline)
+    // bytes (may be null): algorithmic HBM bytes per class.  ms_b2b (may be null): the launches of each class replayed BACK TO BACK
+    // between one event pair (3 rounds, averaged) - per-launch durations without the 3-5 us that an event pair adds to every launch
+    // it brackets in the per-op pass; inputs are whatever the full pass left in the buffers.
     int eps_profile(const float* x, const int64_t* t, float* out, hipStream_t stream, double* ms, double* flops, int* launches,
-                    const char* csv_path = nullptr) {
+                    const char* csv_path = nullptr, double* bytes = nullptr, double* ms_b2b = nullptr) {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_eps_profile before mkd_prepare");
         io_x = x; io_t = t; io_out = out;
         run_main = stream; run_serial = true;          // profile on ONE stream: per-launch times are not overlapped
@@ -1571,6 +1578,26 @@ struct mkd_ctx {
             if (csv) fprintf(csv, "%zu,%s,%s,%.5f,%.4f,%d\n", i, kind_name(op.kind).c_str(), op.label.c_str(), dt, op.flops / 1e9, op.sid);
         }
         if (csv) fclose(csv);
+        if (bytes) {
+            for (int k = 0; k < K_COUNT; ++k) bytes[k] = 0;
+            for (auto& op : plan_eps) bytes[op.kind] += op.bytes;
+        }
+        if (ms_b2b && !rc) {
+            constexpr int ROUNDS = 3;
+            for (int k = 0; k < K_COUNT && !rc; ++k) {
+                ms_b2b[k] = 0;
+                if (!launches[k]) continue;
+                for (int r = 0; r <= ROUNDS && !rc; ++r) {          // round 0 warms up
+                    if (hipEventRecord(ev[0], stream) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipEventRecord");
+                    for (size_t i = 0; i < n && !rc; ++i)
+                        if (plan_eps[i].kind == k && plan_eps[i].launches > 0) rc = plan_eps[i].fn(stream);
+                    if (!rc && (hipEventRecord(ev[1], stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) rc = mkd_fail(MKD_ERR_HIP, "class replay");
+                    float dt = 0.f;
+                    if (!rc && hipEventElapsedTime(&dt, ev[0], ev[1]) != hipSuccess) rc = mkd_fail(MKD_ERR_HIP, "hipEventElapsedTime");
+                    if (r > 0) ms_b2b[k] += dt / ROUNDS;
+                }
+            }
+        }
         for (auto& e : ev) hipEventDestroy(e);
         return rc;
     }
@@ -2347,6 +2374,12 @@ int mkd_eps_profile(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_o
                     double* flops_per_kind, int* launches_per_kind, const char* csv_path) {
     if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile: null argument");
     return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind, csv_path);
+}
+int mkd_eps_profile2(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_out, void* stream, double* ms_per_kind,
+                     double* flops_per_kind, int* launches_per_kind, double* bytes_per_kind, double* ms_back_to_back_per_kind, const char* csv_path) {
+    if (!ctx || !ms_per_kind || !flops_per_kind || !launches_per_kind) return mkd_fail(MKD_ERR_ARG, "mkd_eps_profile2: null argument");
+    return ctx->eps_profile(x, t, eps_out, (hipStream_t)stream, ms_per_kind, flops_per_kind, launches_per_kind, csv_path, bytes_per_kind,
+                            ms_back_to_back_per_kind);
 }
 int mkd_vae_configure(mkd_ctx* ctx, const mkd_vae_config* cfg) {
     if (!ctx || !cfg) return mkd_fail(MKD_ERR_ARG, "mkd_vae_configure: null argument");

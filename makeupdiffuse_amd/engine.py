@@ -401,17 +401,20 @@ class MkdEngine:
         return out
 
     def eps_profile(self, x: torch.Tensor, t: torch.Tensor, csv_path: Optional[str] = None) -> Dict[str, Dict[str, float]]:
-        """One eps with HIP events around every launch group -> {kernel class: {ms, flops, launches}}."""
+        """One eps with HIP events around every launch group -> {kernel class: {ms, flops, launches, bytes, ms_b2b}}: ``bytes`` =
+        algorithmic HBM bytes of the memory-bound classes, ``ms_b2b`` = the class's launches replayed back to back between one
+        event pair (no per-launch event overhead)."""
         x = _f32c(x, self.device)
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         out = torch.empty((self.batch, self.cfg.out_channels, *self.latent_hw), device=self.device, dtype=torch.float32)
         n = self.lib.mkd_kind_count()
-        ms = (C.c_double * n)(); fl = (C.c_double * n)(); ln = (C.c_int * n)()
+        ms = (C.c_double * n)(); fl = (C.c_double * n)(); ln = (C.c_int * n)(); by = (C.c_double * n)(); b2b = (C.c_double * n)()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mkd_eps_profile(self._ctx, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
-                                                C.c_void_p(out.data_ptr()), C.c_void_p(_stream()), ms, fl, ln,
-                                                None if csv_path is None else csv_path.encode()), 'mkd_eps_profile')
-        return {self.lib.mkd_kind_name(k).decode(): {'ms': ms[k], 'flops': fl[k], 'launches': ln[k]} for k in range(n)}
+            _lib.check(self.lib.mkd_eps_profile2(self._ctx, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(_stream()), ms, fl, ln, by, b2b,
+                                                 None if csv_path is None else csv_path.encode()), 'mkd_eps_profile2')
+        return {self.lib.mkd_kind_name(k).decode(): {'ms': ms[k], 'flops': fl[k], 'launches': ln[k], 'bytes': by[k], 'ms_b2b': b2b[k]}
+                for k in range(n)}
 
     # ---- introspection -----------------------------------------------------------------------------
     def eps_flops(self) -> float:

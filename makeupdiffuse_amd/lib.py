@@ -68,6 +68,8 @@ SIGNATURES = {
     'mkd_kind_count': (_I, []),
     'mkd_kind_name': (C.c_char_p, [_I]),
     'mkd_eps_profile': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.c_char_p]),
+    'mkd_eps_profile2': (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double), C.c_char_p]),
     'mkd_eps_flops': (C.c_double, [_P]),
     'mkd_eps_launches': (_I, [_P]),
     'mkd_step_launches': (_I, [_P]),

@@ -99,6 +99,7 @@ def test_bench_self_launches_two_ranks_on_one_card_in_rehearsal_mode():
     assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == 'gloo' and out['rehearsal_single_device'] is True
     assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak' and out['value'] > 0
     assert out['roofline']['frac'] > 0 and len(out['devices']) == 1
+    assert out['roofline_hbm']['bound'] == 'hbm' and 0 < out['roofline_hbm']['frac'] < 1 and out['roofline_hbm']['bytes_per_launch'] > 0
 
 
 def test_rccl_group_of_one_on_the_card():
