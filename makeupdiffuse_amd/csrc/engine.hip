@@ -116,7 +116,8 @@ struct Op {
     int edge_from = -1, edge_to = -1; bool edge_in_graph = false;       // cross-stream edge ops (op_edge)
 };
 
-// kinds: [0, 32) conv GEMM by tile config, [32, 64) linear GEMM by tile config, then the rest
+// kinds: [K_GEMM_CONV, K_GEMM_LIN) conv GEMM by tile config, [K_GEMM_LIN, K_GROUPNORM) linear GEMM by tile config (both ranges
+// must hold gemm_num_tile_cfgs() entries: checked in mkd_ctx_create), then the rest
 enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 48, K_GROUPNORM = 96, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
@@ -1804,6 +1805,7 @@ struct mkd_ctx {
                 step_graph_gen = plan_generation; step_graph_cfg = (int)cfg_on; step_graph_scale = cfg_scale;
                 step_graph_temb = (int)temb_skip; step_graph_batch = batch;
             }
+            // (multi_graph needs no key of its own: whenever step_graph's key above changes, drop_graph() destroys both)
             // MKD_GRAPH_STEPS = k > 1: k consecutive steps captured as ONE graph (the step reads its index from the device-resident
             // counter, so the same capture repeated k times is k different steps); the remainder runs on the single-step graph
             // (default 5: a graph boundary costs ~30 us; batch 8: 5.85 -> 5.82 ms per evaluation, batch 1: 2.99 -> 2.97)
@@ -2281,6 +2283,8 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mkd_fail(MKD_ERR_HIP, "no HIP device visible: libmkd has no CPU path");
+    if (gemm_num_tile_cfgs() > K_GEMM_LIN - K_GEMM_CONV || gemm_num_tile_cfgs() > K_GROUPNORM - K_GEMM_LIN)
+        return mkd_fail(MKD_ERR_STATE, "kernel-class table too small for the tile configurations of kernels_gemm.hip (OpKind)");
     mkd_ctx* c = new mkd_ctx();
     c->cfg = *cfg;
     if (const char* fl = getenv("MKD_FUSE_LN")) c->fuse_ln = fl[0] == '1';
@@ -2466,7 +2470,7 @@ int mkd_gemm_groupnorm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
                             int K, int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int stride, int up, int splitk,
                             int rows_per_sample, const float* gamma, const float* beta, float eps, int silu, uint16_t* y, int ld_y,
                             void* stream) {
-    if (!A || !W || !C || !gamma || !beta || !y) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: null pointer");
+    if (!A || !W || (!C && write_raw) || !gamma || !beta || !y) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: null pointer");
     if (rows_per_sample <= 0 || M % rows_per_sample) return mkd_fail(MKD_ERR_ARG, "mkd_gemm_groupnorm_bf16: M must be a multiple of rows_per_sample");
     if (!g_zero) {
         MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));

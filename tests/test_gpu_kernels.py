@@ -600,6 +600,13 @@ def test_splitk_conv_feeds_groupnorm_from_its_slabs(B, H, W_, Cin, Cout, splitk,
     assert rc == 0, lib.mkd_last_error()
     sync()
     assert torch.equal(y3, y) and (junk == 7.0).all()
+    # ... and C may then be NULL, as mkd.h says (valid only when write_raw != 0)
+    y4 = torch.zeros_like(y)
+    rc = lib.mkd_gemm_groupnorm_bf16(P(xn), Cin, P(wp), K, P(bias), P(rowbias), Cout if rowb else 0, hw, P(R), Cout if res else 0, 1.0, None, Cout, 0,
+                                     M, Cout, K, 1, B, H, W_, Cin, H, W_, 1, 0, splitk, hw, P(gamma), P(beta), eps, silu, P(y4), Cout, None)
+    assert rc == 0, lib.mkd_last_error()
+    sync()
+    assert torch.equal(y4, y)
 
 
 @pytest.mark.parametrize('cfg', [-1, 0, 1, 3, 4, 5, 14, 15, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29])
@@ -637,6 +644,42 @@ def test_gemm_layernorm_on_the_fly(cfg, M, d, N2, act):
     if act == 2:
         ref = ref[:, :inner] * F.gelu(ref[:, inner:])
     assert_close_bf16(out, ref, rel=8e-3, what=f'on-the-fly layernorm gemm cfg {cfg}')
+
+
+@pytest.mark.parametrize('cfg', [1, 5, 19, 24])
+@pytest.mark.parametrize('offset,std', [(50.0, 0.5), (100.0, 1.0), (-30.0, 0.25)])
+def test_gemm_layernorm_on_the_fly_rows_with_mean_far_above_std(cfg, offset, std):
+    """the on-the-fly form takes var = E[x^2] - mean^2 from single-pass fp32 MFMA sums and applies rstd * (acc - mu * s) to
+    accumulators of RAW rows; rows with |mean| >> std lose precision to cancellation in both.  Rows at mean / std = 100 - 120 (far
+    beyond what a residual stream after attention / FF carries) against torch layer_norm -> linear on the same bf16 inputs, and
+    against the two-kernel path (layernorm_kernel, then the plain GEMM)."""
+    lib = L()
+    M, d, N2 = 256, 320, 320
+    g = torch.Generator().manual_seed(int(abs(offset)) + cfg)
+    A = bf(offset + std * torch.randn(M, d, generator=g))
+    W2 = (torch.randn(N2, d, generator=g) / math.sqrt(d)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV); beta = (0.2 * torch.randn(d, generator=g)).to(DEV)
+    b2 = torch.randn(N2, generator=g).to(DEV)
+    Wf = torch.empty(N2, d, device=DEV, dtype=torch.bfloat16); s = torch.empty(N2, device=DEV); bfold = torch.empty(N2, device=DEV)
+    assert lib.mkd_fold_layernorm(P(W2), P(gamma), P(beta), P(b2), N2, d, P(Wf), 0, 1, P(s), P(bfold), None) == 0
+    out = torch.zeros(M, N2, device=DEV, dtype=torch.bfloat16)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        assert lib.mkd_gemm_ln_bf16(P(A), d, P(Wf), d, P(bfold), P(s), None, 0, 1e-5, 0, P(out), N2, M, N2, d, None) == 0, lib.mkd_last_error()
+        sync()
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    ref = F.linear(F.layer_norm(A.float(), (d,), gamma, beta, 1e-5), W2, b2)
+    # two-kernel path: LayerNorm kernel (bf16 out), then the plain GEMM on the unfolded weights
+    y = torch.empty(M, d, device=DEV, dtype=torch.bfloat16); two = torch.zeros(M, N2, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_layernorm(P(A), P(gamma), P(beta), 1e-5, P(y), M, d, None) == 0
+    W2b = bf(W2)
+    assert lib.mkd_gemm_bf16(P(y), d, P(W2b), d, P(b2), None, 0, 1, None, 0, 1.0, 0, P(two), N2, 0, M, N2, d, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, None) == 0
+    sync()
+    r_fly, r_two = rel_l2(out, ref), rel_l2(two, ref)
+    print(f'mean {offset} std {std} cfg {cfg}: on-the-fly rel-L2 {r_fly:.3e}, LayerNorm kernel + GEMM {r_two:.3e}')
+    assert torch.isfinite(out.float()).all() and r_fly <= 1.5e-2, r_fly          # (measured on MI355X: printed; the two-kernel path rounds LN(x) to bf16 first)
+    assert r_fly <= 3.0 * r_two + 2e-3
 
 
 @pytest.mark.parametrize('mode', [1, 2])
