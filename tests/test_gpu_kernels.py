@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import DEV, L, P, assert_close_bf16, bf, sync
+from gpu_util import DEV, L, P, assert_close_bf16, bf, rel_l2, sync
 
 pytestmark = pytest.mark.gpu
 
@@ -678,7 +678,7 @@ def test_gemm_layernorm_on_the_fly_rows_with_mean_far_above_std(cfg, offset, std
     sync()
     r_fly, r_two = rel_l2(out, ref), rel_l2(two, ref)
     print(f'mean {offset} std {std} cfg {cfg}: on-the-fly rel-L2 {r_fly:.3e}, LayerNorm kernel + GEMM {r_two:.3e}')
-    assert torch.isfinite(out.float()).all() and r_fly <= 1.5e-2, r_fly          # (measured on MI355X: printed; the two-kernel path rounds LN(x) to bf16 first)
+    assert torch.isfinite(out.float()).all() and r_fly <= 6e-3, r_fly          # measured on MI355X: 2.0e-3 - 2.1e-3 (the two-kernel path, which rounds LN(x) to bf16 first: 2.4e-3)
     assert r_fly <= 3.0 * r_two + 2e-3
 
 
