@@ -336,6 +336,8 @@ def main():
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
                      'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None},
             'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items() if v['ms'] > 0},
+            # the same classes with their launches replayed back to back between one event pair (no per-launch event overhead)
+            'kernel_classes_ms_per_eval_back_to_back': {k: round(v['ms_b2b'], 4) for k, v in prof.items() if v['ms_b2b'] > 0},
         }
         if want_cpu:
             eng.prepare(hint[:1], ctx[:1])
