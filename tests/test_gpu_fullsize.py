@@ -287,3 +287,32 @@ def test_full_size_interpolation_ten_step_trajectory_vs_oracle():
     print(f'alpha 0 vs alpha 1 latents: rel-L2 {d01:.3e}; alpha 0.4 vs alpha 0: {rel(out, ends[0]):.3e}, vs alpha 1: {rel(out, ends[1]):.3e}')
     assert d01 > 1e-3 and not torch.equal(out, ends[0]) and not torch.equal(out, ends[1]), 'the second reference must move the trajectory'
     eng.close()
+
+
+def test_full_size_grouped_encoder_equals_two_chains_bit_for_bit(monkeypatch):
+    """MKD_ENC_GROUP at BASELINE size (batch 8, 256x256, the 1.22 G-parameter nets): every tile configuration the tuned table picks
+    for the encoder phase - LDS-staged convolutions, split-K with its reduce, slab-fed GroupNorm, in-block K splits, on-the-fly
+    LayerNorm - run as 2-problem grouped launches gives the eps and the 5-step latent of the two-chain plan BIT FOR BIT, after
+    NaN-poisoning, with 140+ launches fewer per step."""
+    g = torch.Generator().manual_seed(7)
+    B = 8
+    x = torch.randn(B, 4, 32, 32, generator=g); hint = torch.rand(B, 6, 256, 256, generator=g)
+    ctx = torch.randn(B, 77, 768, generator=g); t = torch.tensor([981, 901, 701, 501, 401, 301, 101, 1])
+    sch = DDIMSchedule().make_ddim(5)
+    args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
+    res = {}
+    for group in (0, 1):
+        monkeypatch.setenv('MKD_ENC_GROUP', str(group))
+        eng = MkdEngine(NetConfig())
+        eng.init_random(0, norm_jitter=0.2)
+        eng.prepare(hint, ctx)
+        eng.debug_poison()
+        e = eng.eps(x, t)
+        eng.debug_poison()
+        lat = eng.sample(x, *args, use_graph=True)
+        assert torch.isfinite(e).all() and torch.isfinite(lat).all()
+        res[group] = (e, lat, eng.step_launches())
+        eng.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    print(f'launches per step at batch 8: two chains {res[0][2]}, grouped {res[1][2]}')
+    assert res[1][2] <= res[0][2] - 140
