@@ -482,6 +482,272 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "Register-A" implicit GEMM (round 3): the ACTIVATION operand never touches LDS, and nothing goes through LDS-DMA.
+//
+// gemm_kernel stages both operand tiles through LDS with global_load_lds, and a wave's LDS-DMA transfers complete one after the
+// other (~140-370 cycles per 1 KiB piece, tools/micro/stream_rate3.hip): a K-step of a 128x128 tile asks 8 pieces of
+// every wave - ~1500 cycles for 512 cycles of MFMA work.  Here the NW waves of a workgroup split the ROWS of the tile only (wave w
+// owns rows [w TM/NW, +TM/NW) and all TN columns), so an activation fragment belongs to exactly one wave: it is loaded straight
+// from L2 / Infinity Cache into the registers the MFMA reads, in fragment layout (lane (row r, quarter q) of a 16 x 32 fragment
+// holds 8 consecutive k of row r: one global_load_dwordx4, 64 B contiguous per row and instruction), STAGES - 1 K-steps ahead, with
+// plain loads that pipeline.  The WEIGHT tile, shared by all waves (TN x 64 bf16 = 8-20 KiB per K-step, TN/8/NW 1 KiB pieces per
+// wave), is loaded the same way - registers first, coalesced 128 B rows - and written to a double-buffered LDS tile one K-step ahead
+// of its use (ds_write_b128 under the previous step's MFMAs), XOR-swizzled as in gemm_kernel.
+// All loads are ORDINARY loads that the compiler sees: its own counted s_waitcnt vmcnt (exact for in-order VGPR loads) guards every
+// use of a prefetched register - including the register COPIES it places at control-flow joins, which is what broke two earlier
+// forms of this kernel that issued the loads as inline asm with hand-counted waits (a copy of a register whose load is still in
+// flight reads stale bits, and nothing tells the compiler that the load is pending: sporadic NaNs, tools/dbg_ra.py).
+// One s_barrier per K-step.  Epilogue as gemm_kernel's plain forms (bias, per-sample row bias, scale, residual, SiLU / quick-GELU /
+// GEGLU, fp32 output, split-K slabs); fused LayerNorm / statistics variants stay on gemm_kernel (kTileBase).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (explicitly GLOBAL: a pointer that went through select_src's opaque integer select would otherwise be loaded with flat_load, which
+// counts in lgkmcnt as well and turns every wait into a drain)
+__device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
+    dst = *(const __attribute__((address_space(1))) u32x4*)(unsigned long long)p;
+}
+template <int TM, int TN, int NW, int CONV, int STAGES>
+__global__ __launch_bounds__(64 * NW) void gemm_ra_kernel(const GemmArgs2 pg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x [TN][64] bf16: W tile of the current and of the next K-step
+    const int grp = (int)blockIdx.z >= pg.g[0].gz ? 1 : 0;
+    const GemmArgs& p = pg.g[grp];
+    constexpr int WSB = TN * 128;         // bytes of one W tile (TN rows x 64 bf16)
+    constexpr int WP = TN / 8 / NW;       // W pieces (8 rows x 128 B) per wave and K-step
+    constexpr int RW = TM / NW;           // rows of a wave
+    constexpr int MI = RW / 16;           // A fragments of a wave
+    constexpr int NI = TN / 16;           // W fragments (every wave reads all of them)
+    constexpr int LPT = WP + 2 * MI;      // loads per wave per K-step (exact)
+    static_assert((WP == 1 || WP == 2 || WP == 4 || WP == 5) && (MI == 2 || MI == 4) && NI >= 1 && (NW == 4 || NW == 8) && STAGES >= 3 && STAGES <= 4, "tile / wave layout");
+    static_assert((STAGES - 1) * LPT < 64, "vmcnt: every prefetched load must be countable");
+
+    const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
+    const int lda = p.lda, ldw = p.ldw, M = p.M, N = p.N, K = p.K;
+    const int Hin = p.Hin, Win = p.Win, Cin = p.Cin, Hout = p.Hout, Wout = p.Wout, cstride = p.stride, up = p.up;
+    const int splitk = p.splitk, per = p.ksteps_per_split;
+    float* const ws = p.ws;
+    const Epilogue epi = make_epilogue(p);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bx, by, bz;
+    xcd_tile_order(p.xcd_mode, p.gz, grp, bx, by, bz);
+    const int m0 = bx * TM, n0 = by * TN;
+    const int nk_total = (K + BK - 1) / BK;
+    const int kt_begin = bz * per;
+    const int kt_end = min(nk_total, kt_begin + per);
+
+    // ---- W pieces: lane (lrow = lane >> 3, chunk c = lane & 7) of piece i loads 16 B of tile row 8 (w + NW i) + lrow: 128 B per row,
+    //      coalesced; it lands in LDS at row * 128 + ((c ^ key) << 4), key = (row >> 1) & 7 (the swizzle gemm_kernel reads with) ----
+    const int lrow = lane >> 3, lc = lane & 7;
+    const int key = (4 * (w & 1) + (lane >> 4)) & 7;          // == ((tile_row >> 1) & 7) for every piece of this wave (NW even)
+    size_t woff[WP];
+    bool wok[WP];
+    int wlds[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = 8 * (w + NW * i) + lrow;
+        const int n = n0 + r;
+        wok[i] = n < N;
+        woff[i] = (size_t)n * ldw + lc * 8;
+        wlds[i] = r * 128 + ((lc ^ key) << 4);
+    }
+    // ---- A fragments: lane (frow, fq) of fragment mi holds row m0 + w RW + 16 mi + frow, k = 64 kt + 32 kk + 8 fq .. +8 ----
+    const int frow = lane & 15, fq = lane >> 4;
+    size_t aoff[MI];               // LINEAR: element offset of the row (+ the lane's k quarter);  CONV: pixel-index base of the sample
+    int uy0[MI], ux0[MI];
+    bool aok[MI];
+    const int Hup = Hin << up, Wup = Win << up;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + w * RW + mi * 16 + frow;
+        aok[mi] = m < M;
+        if (CONV) {
+            const int hw = Hout * Wout;
+            const int mm = aok[mi] ? m : 0;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / Wout;
+            const int ox = rem - oy * Wout;
+            aoff[mi] = (size_t)b * Hin * Win;
+            uy0[mi] = oy * cstride - 1;
+            ux0[mi] = ox * cstride - 1;
+        } else {
+            aoff[mi] = (size_t)m * lda + fq * 8;
+            uy0[mi] = ux0[mi] = 0;
+        }
+    }
+
+    u32x4 wr[STAGES][WP];          // W pieces of up to STAGES K-steps in flight (slot indices are compile-time after unrolling)
+    u32x4 xr[STAGES][MI][2];       // A fragments of the same K-steps
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) {
+#pragma unroll
+        for (int i = 0; i < WP; ++i) wr[s][i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { xr[s][mi][0] = u32x4{0u, 0u, 0u, 0u}; xr[s][mi][1] = u32x4{0u, 0u, 0u, 0u}; }
+    }
+    // ALWAYS exactly LPT loads (W pieces first), also for K-steps past this block's range (zero page): the number of loads in flight
+    // behind any K-step is then the same on every path, which is what lets the compiler's s_waitcnt vmcnt be a counted one
+    // instead of a drain (a wait after a join must hold for the path with the FEWEST younger loads)
+    auto issue = [&](int slot, int kt) {
+        const int kw = kt < kt_end ? kt * BK : K;          // (K: every chunk out of range -> zero page)
+#pragma unroll
+        for (int i = 0; i < WP; ++i) gload16(wr[slot][i], select_src(gW + woff[i] + kw, gZ, wok[i] && kw + lc * 8 < K));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = kw + 32 * kk + 8 * fq;
+            int ci = 0, ky = 0, kx = 0;
+            if (CONV) {
+                const int tap = k / Cin;
+                ci = k - tap * Cin;
+                ky = (tap * 11) >> 5;
+                kx = tap - 3 * ky;
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const bf16_t* real;
+                bool ok;
+                if (CONV) {
+                    const int uy = uy0[mi] + ky, ux = ux0[mi] + kx;
+                    ok = k < K && aok[mi] && (unsigned)uy < (unsigned)Hup && (unsigned)ux < (unsigned)Wup;
+                    real = gA + ((aoff[mi] + (size_t)((uy >> up) * Win + (ux >> up))) * lda + ci);
+                } else {
+                    ok = k < K && aok[mi];
+                    real = gA + aoff[mi] + kw + 32 * kk;
+                }
+                gload16(xr[slot][mi][kk], select_src(real, gZ, ok));
+            }
+        }
+    };
+    // the W pieces of the K-step in `slot` into an LDS tile (the compiler's own counted s_waitcnt vmcnt precedes the first use of wr)
+    auto land = [&](int slot, char* wbuf) {
+#pragma unroll
+        for (int i = 0; i < WP; ++i) *(u32x4*)(wbuf + wlds[i]) = wr[slot][i];
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int slot, const char* wsm) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = 4 * kk + fq;
+            bf16x8 wf[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = ni * 16 + frow;
+                wf[ni] = *(const bf16x8*)(wsm + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], __builtin_bit_cast(bf16x8, xr[slot][mi][kk]), acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    const int ntile = kt_end - kt_begin;
+    if (ntile > 0) {
+        // K-steps 0 .. STAGES-2 in flight, K-step 0 landed and in LDS buffer 0.  The loop body is STAGES K-steps without a branch
+        // (register slots are compile-time); K-steps past the end multiply zeros (at most STAGES - 1 of them per workgroup).
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) issue(s, kt_begin + s);
+        asm volatile("" ::: "memory");
+        land(0, smem);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int i0 = 0; i0 < ntile; i0 += STAGES) {
+#pragma unroll
+            for (int j = 0; j < STAGES; ++j) {
+                const int i = i0 + j;
+                char* const cur = smem + (i & 1) * WSB;
+                char* const nxt = smem + ((i + 1) & 1) * WSB;
+                issue((j + STAGES - 1) % STAGES, kt_begin + i + STAGES - 1);      // (slot of K-step i - 1: consumed)
+                asm volatile("" ::: "memory");                 // (the prefetch stays ahead of this step's LDS traffic and MFMAs)
+                // K-step i + 1 into the other LDS buffer (read last during K-step i - 1: every wave is past that barrier), under this step's MFMAs
+                land((j + 1) % STAGES, nxt);
+                compute(j, cur);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // next W tile visible to all waves; all reads of the current one done
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+
+    // epilogue operands (after the K loop: ordinary compiler-managed loads must not sit among the counted ones)
+    const bool pre = splitk == 1;
+    f32x4 pbias[NI];
+    U16x4 pres[NI][MI];
+    if (pre) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + ni * 16 + 4 * fq;
+            pbias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (epi.bias && n < N) pbias[ni] = *(const f32x4*)(epi.bias + n);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + w * RW + mi * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pres[ni][mi].v[j] = 0;
+                if (epi.R && n < N && m < M) pres[ni][mi] = *(const U16x4*)(epi.R + (size_t)m * epi.ldr + n);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds D[n = 4 fq + r][m = frow] of every (ni, mi) fragment (as gemm_kernel) ----
+    const int wr0 = m0 + w * RW;
+    if (pre && epi.act == 0 && !epi.out_f32) {
+        if (wr0 >= M) return;
+        int rb_b = -1;
+        bool ok = true;
+        if (epi.rowbias) {
+            const int wr1 = min(wr0 + RW, M) - 1;
+            rb_b = wr0 / epi.rpb;
+            ok = rb_b == wr1 / epi.rpb;
+        }
+        if (ok) {
+            f32x4 prb[NI];
+            if (rb_b >= 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + ni * 16 + 4 * fq;
+                    prb[ni] = n < N ? *(const f32x4*)(epi.rowbias + (size_t)rb_b * epi.ldrb + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = wr0 + mi * 16 + frow;
+                if (m >= M) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + ni * 16 + 4 * fq;
+                    if (n >= N) continue;
+                    if (rb_b >= 0) epilogue_fast_store<true>(epi, m, n, acc[ni][mi], pbias[ni], prb[ni], pres[ni][mi]);
+                    else epilogue_fast_store<false>(epi, m, n, acc[ni][mi], pbias[ni], pbias[ni], pres[ni][mi]);
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = wr0 + mi * 16 + frow;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + ni * 16 + 4 * fq;
+            if (n >= N) continue;
+            if (splitk > 1) *(f32x4*)(ws + ((size_t)bz * M + m) * N + n) = acc[ni][mi];
+            else epilogue_write(epi, m, n, epilogue_value_pre(epi, m, n, acc[ni][mi], pbias[ni], pres[ni][mi]));
+        }
+    }
+}
+
 // split-K reduce + epilogue: thread = (row m, 4 columns); slabs summed 4 at a time with independent loads.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs2 pg) {
     const GemmArgs& p = pg.g[blockIdx.z];      // grouped launch: z selects the problem
@@ -614,21 +880,29 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs2
 //   38..40: LDS-staged 3x3 conv tiles with EIGHT waves (kernels_conv.hip): 128x64, 64x128, 128x128; 41: 256x64 with 8 waves (gather /
 //       linear, plain epilogue only); 42 / 43: LDS-staged 256x128 / 128x128 with SIXTEEN waves.  Inside the sampling loop the whole-loop tuner (tools/tune_wall.py) moves the heavy shapes onto the
 //       eight-wave tiles although they are not faster alone: half the LDS-DMA pieces per wave and K-step.
-constexpr int N_TILE_CFG = 44;
+//   44..49: register-A tiles (gemm_ra_kernel: activations straight into the MFMA's registers, only the weight tile through LDS):
+//       256x64 and 256x128 with 8 waves (32 rows each), 128x128 / 128x64 / 128x160 with 4 waves, 256x64 with 4 waves (64 rows each).
+constexpr int N_TILE_CFG = 50;
 static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32,
-                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128};
+                                       32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128,
+                                       256, 256, 128, 128, 128, 256};
 static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32,
-                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128};
-static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0};
+                                       32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128,
+                                       64, 128, 128, 64, 160, 64};
+static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                        1, 1, 1, 1, 1, 1};
+static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0,
+                                           1, 1, 1, 1, 1, 1};
 static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4,
-                                          5, 3, 4, 18, 2, 3, 4, 5, 38, 39, 40, 3, 42, 43};
+                                          5, 3, 4, 18, 2, 3, 4, 5, 38, 39, 40, 3, 42, 43,
+                                          3, 1, 1, 3, 14, 3};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
                                                   "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32",
                                                   "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2",
                                                   "64x64_s2", "128x64_s2", "64x128_s2", "64x32_s2", "128x128_w8", "128x64_w8", "64x128_w8", "64x64_w8",
-                                                  "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8", "patch256x128_w16", "patch128x128_w16"};
+                                                  "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8", "patch256x128_w16", "patch128x128_w16",
+                                                  "ra256x64_w8", "ra256x128_w8", "ra128x128", "ra128x64", "ra128x160", "ra256x64"};
 static bool is_patch_cfg(int c) { return (c >= 6 && c <= 11) || (c >= 38 && c <= 40) || c == 42 || c == 43; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -909,6 +1183,17 @@ bool gemm_same_geometry(const GemmArgs& a, const GemmArgs& b) {
            (a.bias != nullptr) == (b.bias != nullptr);
 }
 
+template <int TM, int TN, int NW, int STAGES>
+static int launch_tile_ra(const GemmArgs& a, int splitk, hipStream_t stream, const GemmArgs* second) {
+    const GemmArgs2 ag = gemm_pack2(a, second, splitk);
+    const size_t lds = (size_t)2 * TN * 128;
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, splitk * (second ? 2 : 1));
+    dim3 block(64 * NW);
+    if (a.conv) hipLaunchKernelGGL((gemm_ra_kernel<TM, TN, NW, 1, STAGES>), grid, block, lds, stream, ag);
+    else        hipLaunchKernelGGL((gemm_ra_kernel<TM, TN, NW, 0, STAGES>), grid, block, lds, stream, ag);
+    return 0;
+}
+
 int launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second) {
     GemmArgs b;
     if (second) {
@@ -981,6 +1266,12 @@ int launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second) {
         case 36: rc = launch_tile_light<64, 128, 2, 4, 3>(a, g.splitk, stream, sp); break;
         case 37: rc = launch_tile_light<64, 64, 2, 4, 4>(a, g.splitk, stream, sp); break;
         case 41: rc = launch_tile_light<256, 64, 4, 2, 3>(a, g.splitk, stream, sp); break;
+        case 44: rc = launch_tile_ra<256, 64, 8, 4>(a, g.splitk, stream, sp); break;
+        case 45: rc = launch_tile_ra<256, 128, 8, 3>(a, g.splitk, stream, sp); break;
+        case 46: rc = launch_tile_ra<128, 128, 4, 3>(a, g.splitk, stream, sp); break;
+        case 47: rc = launch_tile_ra<128, 64, 4, 4>(a, g.splitk, stream, sp); break;
+        case 48: rc = launch_tile_ra<128, 160, 4, 3>(a, g.splitk, stream, sp); break;
+        case 49: rc = launch_tile_ra<256, 64, 4, 3>(a, g.splitk, stream, sp); break;
         default: rc = launch_tile<64, 64, 2, 2, 4>(a, g.splitk, stream, sp); break;
     }
     if (rc) return rc;
