@@ -118,7 +118,7 @@ struct Op {
 
 // kinds: [K_GEMM_CONV, K_GEMM_LIN) conv GEMM by tile config, [K_GEMM_LIN, K_GROUPNORM) linear GEMM by tile config (both ranges
 // must hold gemm_num_tile_cfgs() entries: checked in mkd_ctx_create), then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 48, K_GROUPNORM = 96, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 64, K_GROUPNORM = 128, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
     static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
