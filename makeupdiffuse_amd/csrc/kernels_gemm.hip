@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
     constexpr int XP = TM / 8 / NW;       // X pieces per wave
     constexpr int NI = TN / WN / 16;      // W fragments (16 rows) per wave
     constexpr int MI = TM / WM / 16;      // X fragments (16 rows) per wave
-    static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8), "tile/wave layout");
+    static_assert(WP >= 1 && XP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8 || NW == 16), "tile/wave layout");
     static_assert(STAGES >= 2 && STAGES <= 6 && 4 * (XP + WP) + (LN > 0 ? MI * LN : 0) < 64, "vmcnt immediates");
     static_assert(!(LN && GNS), "fused LayerNorm and GroupNorm statistics are separate kernels");
     // LN < 0: LayerNorm of the A rows "on the fly": the GEMM runs on the RAW rows with gamma-folded weights (as LN > 0) and takes
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
     // Epilogue operands (bias, residual) are fetched FIRST: older than every tile load, they retire before tile 0 is waited on
     // (vmcnt is in-order, so the counted waits below are unaffected) and their latency hides under the K loop instead of being
     // paid after it - these layers are latency-bound and K is often 5 steps.
-    const bool pre = splitk == 1 && !LN && kg == 0;
+    const bool pre = splitk == 1 && !LN && kg == 0 && NW < 16;          // (16 waves: 128 registers per wave, no room for the prefetched operands)
     // GNS: (sample, group) accumulator of this tile behind the ring, zeroed here, long before the epilogue (K-loop barriers between)
     constexpr int GTAIL = 4096;
     long long* const gacc = (long long*)(smem + STAGES * STAGE);
@@ -882,27 +882,29 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gn_kernel(const GemmArgs2
 //       eight-wave tiles although they are not faster alone: half the LDS-DMA pieces per wave and K-step.
 //   44..49: register-A tiles (gemm_ra_kernel: activations straight into the MFMA's registers, only the weight tile through LDS):
 //       256x64 and 256x128 with 8 waves (32 rows each), 128x128 / 128x64 / 128x160 with 4 waves, 256x64 with 4 waves (64 rows each).
-constexpr int N_TILE_CFG = 50;
+//   50: 256x256 with SIXTEEN waves (64x64 each), 2 stages (128 KiB LDS): 128 FLOP per byte pulled out of L2, for the few GEMMs whose M and N
+//       both allow it (the K loops of the gather / linear kernel run at three quarters of the L2 -> CU rate: DESIGN.md 4.5); plain epilogue only.
+constexpr int N_TILE_CFG = 51;
 static const int kTileM[N_TILE_CFG] = {256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32,
                                        32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128,
-                                       256, 256, 128, 128, 128, 256};
+                                       256, 256, 128, 128, 128, 256, 256};
 static const int kTileN[N_TILE_CFG] = {128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32,
                                        32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128,
-                                       64, 128, 128, 64, 160, 64};
+                                       64, 128, 128, 64, 160, 64, 256};
 static const int kTileKW[N_TILE_CFG] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 2, 4, 2, 4, 2, 4, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                        1, 1, 1, 1, 1, 1};
+                                        1, 1, 1, 1, 1, 1, 1};
 static const int kTileLight[N_TILE_CFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0,
-                                           1, 1, 1, 1, 1, 1};
+                                           1, 1, 1, 1, 1, 1, 1};
 static const int kTileBase[N_TILE_CFG] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 19, 19, 18, 18, 5, 5, 17, 17, 3, 4,
                                           5, 3, 4, 18, 2, 3, 4, 5, 38, 39, 40, 3, 42, 43,
-                                          3, 1, 1, 3, 14, 3};
+                                          3, 1, 1, 3, 14, 3, 0};
 static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x128_s2", "128x64", "64x128", "64x64",
                                                   "patch256x128", "patch256x64", "patch128x128", "patch128x64",
                                                   "patch64x128", "patch64x64", "64x64_s6", "64x128_s5", "64x160", "128x160", "64x160_s2", "32x64", "64x32", "32x32",
                                                   "32x32_k2", "32x32_k4", "64x32_k2", "64x32_k4", "64x64_k2", "64x64_k4", "32x64_k2", "32x64_k4", "128x64_k2", "64x128_k2",
                                                   "64x64_s2", "128x64_s2", "64x128_s2", "64x32_s2", "128x128_w8", "128x64_w8", "64x128_w8", "64x64_w8",
                                                   "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8", "patch256x128_w16", "patch128x128_w16",
-                                                  "ra256x64_w8", "ra256x128_w8", "ra128x128", "ra128x64", "ra128x160", "ra256x64"};
+                                                  "ra256x64_w8", "ra256x128_w8", "ra128x128", "ra128x64", "ra128x160", "ra256x64", "256x256_w16"};
 static bool is_patch_cfg(int c) { return (c >= 6 && c <= 11) || (c >= 38 && c <= 40) || c == 42 || c == 43; }
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
@@ -1266,6 +1268,7 @@ int launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second) {
         case 36: rc = launch_tile_light<64, 128, 2, 4, 3>(a, g.splitk, stream, sp); break;
         case 37: rc = launch_tile_light<64, 64, 2, 4, 4>(a, g.splitk, stream, sp); break;
         case 41: rc = launch_tile_light<256, 64, 4, 2, 3>(a, g.splitk, stream, sp); break;
+        case 50: rc = launch_tile_light<256, 256, 4, 4, 2>(a, g.splitk, stream, sp); break;
         case 44: rc = launch_tile_ra<256, 64, 8, 4>(a, g.splitk, stream, sp); break;
         case 45: rc = launch_tile_ra<256, 128, 8, 3>(a, g.splitk, stream, sp); break;
         case 46: rc = launch_tile_ra<128, 128, 4, 3>(a, g.splitk, stream, sp); break;

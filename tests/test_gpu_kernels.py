@@ -46,7 +46,7 @@ def test_gemm_linear(M, N, K, splitk):
     assert_close_bf16(out, ref, what=f'gemm {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 48, 49, 50])
 @pytest.mark.parametrize('M,N,K,splitk', [(300, 320, 320, 1), (1000, 640, 1344, 1), (128, 1280, 2560, 4), (77, 64, 64, 1), (256, 1280, 1280, 1), (96, 320, 200, 1)])
 def test_gemm_every_tile_config(cfg, M, N, K, splitk):
     """each gather-GEMM tile / pipeline-depth configuration, incl. K not a multiple of 64 and ragged M/N."""
@@ -122,7 +122,7 @@ def test_gemm_fused_layernorm_chain(M, d, N2, cfg):
     assert_close_bf16(out, ref, rel=8e-3, what='fused layernorm gemm')
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 3, 5, 14, 19, 21, 24, 34, 36, 41, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize('cfg', [0, 1, 3, 5, 14, 19, 21, 24, 34, 36, 41, 44, 45, 46, 47, 48, 49, 50])
 @pytest.mark.parametrize('M,rpb', [(300, 20), (300, 100), (520, 64), (96, 16)])
 def test_gemm_row_bias_on_ragged_and_straddling_tiles(cfg, M, rpb):
     """bias + per-sample row bias + scale + residual (the straight-line epilogue when all rows of a wave lie in one sample, the general
@@ -167,7 +167,7 @@ def test_gemm_epilogue_variants():
     assert (out[:, N:] == 0).all()
 
 
-@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize('cfg', [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 48, 49, 50])
 @pytest.mark.parametrize('B,H,W_,Cin,Cout,stride,up', [(2, 16, 16, 64, 320, 1, 0), (1, 8, 8, 128, 160, 1, 1), (2, 12, 20, 32, 96, 2, 0)])
 def test_gemm_conv3x3_160_wide_tiles(cfg, B, H, W_, Cin, Cout, stride, up):
     lib = L()

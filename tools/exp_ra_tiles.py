@@ -15,7 +15,7 @@ LIN = [(8192, 320, 320), (8192, 2560, 320), (8192, 320, 1600), (8192, 960, 320),
        (512, 10240, 1280), (512, 1280, 6400), (4096, 2560, 320), (4096, 320, 1600)]
 CONV = [(8, 32, 32, 320, 320), (4, 32, 32, 640, 320), (4, 32, 32, 960, 320), (8, 16, 16, 640, 640), (4, 16, 16, 1280, 640), (8, 8, 8, 1280, 1280), (4, 8, 8, 2560, 1280)]
 NPOOL = 12
-RA = [44, 45, 46, 47, 48, 49]
+RA = [int(v) for v in os.environ.get('MKD_EXP_CFGS', '44,45,46,47,48,49').split(',')]          # candidate tile configurations
 SPLITS = [1, 2, 3, 4, 6, 8]
 
 

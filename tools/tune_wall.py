@@ -26,8 +26,8 @@ from makeupdiffuse_amd import lib as mlib  # noqa: E402
 from makeupdiffuse_amd.engine import MkdEngine, NetConfig  # noqa: E402
 from makeupdiffuse_amd.schedule import DDIMSchedule  # noqa: E402
 
-TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128, 256, 256, 128, 128, 128, 256]
-TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128, 64, 128, 128, 64, 160, 64]
+TILE_M = [256, 128, 128, 128, 64, 64, 256, 256, 128, 128, 64, 64, 64, 64, 64, 128, 64, 32, 64, 32, 32, 32, 64, 64, 64, 64, 32, 32, 128, 64, 64, 128, 64, 64, 128, 128, 64, 64, 128, 64, 128, 256, 256, 128, 256, 256, 128, 128, 128, 256, 256]
+TILE_N = [128, 128, 128, 64, 128, 64, 128, 64, 128, 64, 128, 64, 64, 128, 160, 160, 160, 64, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 128, 64, 64, 128, 32, 128, 64, 128, 64, 64, 128, 128, 64, 128, 128, 64, 128, 128, 64, 160, 64, 256]
 KEYS = ('M', 'N', 'K', 'conv', 'stride', 'up', 'Hin', 'Win', 'Cin', 'Hout', 'Wout', 'splitk')
 
 
