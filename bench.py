@@ -90,6 +90,33 @@ def pmc_traffic_bytes_per_launch(kernel_fn):
     return None, None
 
 
+def l2_traffic_per_eval():
+    """L2 -> CU traffic of ONE eps evaluation at batch 8, 256x256, from the committed rocprofv3 summaries: per kernel, (TCC_HIT_sum +
+    TCC_MISS_sum) requests per launch (profiles/r3_pmc_l2_hit.csv, 128 B each) x its launches per evaluation (calls in
+    profiles/r3_kernel_stats_bench_b8_256.csv / the evaluations of that run: one per DDIM update kernel call + the 6
+    evaluation-equivalents of the roofline pass).  None when the summaries are absent."""
+    import csv
+    try:
+        stats = {}
+        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r3_kernel_stats_bench_b8_256.csv'))):
+            n = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+            stats[n] = stats.get(n, 0) + int(r['Calls'])
+        evals = stats.get('ddim_step_state_kernel', 0) + stats.get('ddim_step_kernel', 0) + 6          # (graph replay / eager loop)
+        if evals <= 6:
+            return None
+        req = hit = 0.0
+        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r3_pmc_l2_hit.csv'))):
+            k = r['kernel']
+            if k in ('merge_ff_out_kernel', 'pack_conv_weight_kernel', 'fold_layernorm_kernel') or not (k.split('<')[0] in stats or k in stats):
+                continue                                    # (load-time kernels; torch's own kernels)
+            per_eval = stats.get(k, 0) / evals
+            req += (float(r['avg_TCC_HIT_sum']) + float(r['avg_TCC_MISS_sum'])) * per_eval
+            hit += float(r['avg_TCC_HIT_sum']) * per_eval
+        return {'gb_per_eval': req * 128 / 1e9, 'hit_fraction': hit / req if req else None}
+    except Exception:
+        return None
+
+
 def synth_inputs(lo, hi, res, ctx_dim, device):
     """SURVEY.md §8d synthetic inputs, generated PER SAMPLE so shards do not depend on the world size."""
     h = res // 8
@@ -334,7 +361,10 @@ def main():
                      'launches_per_eval': eng.step_launches(), 'launches_per_standalone_eps': eng.eps_launches(),
                      'device_gb': eng.device_bytes() / 1e9,
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
-                     'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None},
+                     'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None,
+                     # what the cache hierarchy moves per evaluation (committed PMC summaries of the default workload)
+                     'l2_traffic': (lambda t: None if (t is None or args.batch != 8 or args.res != 256 or args.cfg or args.interp) else
+                                    dict(t, tb_per_s_over_the_loop=t['gb_per_eval'] / (loop_ms / evals_per_step), source='profiles/r3_pmc_l2_hit.csv x profiles/r3_kernel_stats_bench_b8_256.csv'))(l2_traffic_per_eval())},
             'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items() if v['ms'] > 0},
             # the same classes with their launches replayed back to back between one event pair (no per-launch event overhead)
             'kernel_classes_ms_per_eval_back_to_back': {k: round(v['ms_b2b'], 4) for k, v in prof.items() if v['ms_b2b'] > 0},
