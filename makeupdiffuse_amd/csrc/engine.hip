@@ -630,9 +630,20 @@ struct mkd_ctx {
         return t;
     }
 
+    // Per-launch XCD tile order (GemmArgs::xcd_mode).  In launch order workgroup (m-tile x, n-tile y) runs on XCD (x + gx y) mod 8: an A
+    // tile is pulled through ONE of the 8 non-coherent L2s (all its n-tiles run there), but every XCD walks ALL n-tiles, i.e. each L2
+    // streams the whole weight matrix from the Infinity Cache - and L2 misses are what this loop waits for (19 GB per evaluation,
+    // DESIGN.md 4.5).  Mode 1 gives every XCD one contiguous run of the tile sequence with m-tiles fastest: a weight tile lives in ONE L2,
+    // an A tile in up to gy of them.  So: mode 1 where the weights outweigh the activations, M <= xcd_auto_ratio * N (both operands have
+    // K columns).  MKD_XCD_AUTO_RATIO (0 = launch order everywhere); measured at batch 8, 256x256, ms per evaluation, two rounds
+    // (tools/exp_r3_xcd_auto.sh): off 5.604 / 5.610, ratio 1 5.557 / 5.549, 2 5.547 / 5.548, 4 5.557 / 5.579, 8 5.570 / 5.564, 16 5.637 /
+    // 5.648 (= mode 1 everywhere, MKD_XCD_MODE=1: 5.645); by M alone (N >= 640): M <= 512 5.576 / 5.564, <= 2048 5.565 / 5.544.
+    // Results do not depend on the order (bit-identical: test_xcd_auto_order_changes_no_bit).
+    float xcd_auto_ratio = getenv("MKD_XCD_AUTO_RATIO") ? (float)atof(getenv("MKD_XCD_AUTO_RATIO")) : 2.0f;
     void op_gemm(GemmArgs a, int force_splitk = 0) {
         a.zero = zero_page;
         a.splitk = force_splitk;
+        if (xcd_auto_ratio > 0.f && !a.xcd_mode && (float)a.M <= xcd_auto_ratio * (float)a.N) a.xcd_mode = 1;
         if (gn_colstats_only && a.gn_stat) {
             GnOut g; g.gst = a.gn_stat; g.cg = a.gn_cg; g.coff = a.gn_coff; g.hw = a.gn_hw;
             a.gn_stat = nullptr;

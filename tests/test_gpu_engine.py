@@ -490,3 +490,25 @@ def test_split_setting_changed_after_prepare_is_loud_then_replanned(monkeypatch)
     eng.prepare(hint, ctx)
     assert torch.equal(eng.eps(x, t), ref)
     eng.close()
+
+
+def test_xcd_auto_order_changes_no_bit(monkeypatch):
+    """MKD_XCD_AUTO_RATIO: the weight-heavy GEMMs / convolutions (M <= ratio x N) walk their tiles in XCD-contiguous runs so that a weight
+    tile is pulled through one L2; the workgroup -> tile map is a permutation, so eps and the 5-step latent are equal BIT FOR BIT to
+    launch order everywhere (ratio 0) and to the remap everywhere (ratio 1e9)."""
+    res = {}
+    for ratio in ('0', '2', '1e9'):
+        monkeypatch.setenv('MKD_XCD_AUTO_RATIO', ratio)
+        eng, G = _small_engine()
+        rep = lambda t: torch.cat([t, t, t[:1]])
+        eng.prepare(rep(G['hint']), rep(G['ctx']))
+        eng.debug_poison()
+        e = eng.eps(rep(G['x']), rep(G['t']))
+        sch = sampler.Schedule().make_ddim(5)
+        eng.prepare(G['hint'], G['ctx'])
+        lat = eng.sample(G['x'], sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas, use_graph=True)
+        res[ratio] = (e, lat)
+        eng.close()
+    check_eps(res['2'][0], torch.cat([G['eps'], G['eps'], G['eps'][:1]]), what='default XCD order')
+    for r in ('0', '1e9'):
+        assert torch.equal(res[r][0], res['2'][0]) and torch.equal(res[r][1], res['2'][1]), f'MKD_XCD_AUTO_RATIO={r} changed the result'

@@ -293,7 +293,8 @@ def test_full_size_grouped_encoder_equals_two_chains_bit_for_bit(monkeypatch):
     """MKD_ENC_GROUP at BASELINE size (batch 8, 256x256, the 1.22 G-parameter nets): every tile configuration the tuned table picks
     for the encoder phase - LDS-staged convolutions, split-K with its reduce, slab-fed GroupNorm, in-block K splits, on-the-fly
     LayerNorm - run as 2-problem grouped launches gives the eps and the 5-step latent of the two-chain plan BIT FOR BIT, after
-    NaN-poisoning, with 140+ launches fewer per step."""
+    NaN-poisoning, with 140+ launches fewer per step.  Third engine: the default plan without the XCD-aware tile order of the weight-heavy
+    layers (MKD_XCD_AUTO_RATIO=0) - a permutation of the tiles, same bits."""
     g = torch.Generator().manual_seed(7)
     B = 8
     x = torch.randn(B, 4, 32, 32, generator=g); hint = torch.rand(B, 6, 256, 256, generator=g)
@@ -301,8 +302,9 @@ def test_full_size_grouped_encoder_equals_two_chains_bit_for_bit(monkeypatch):
     sch = DDIMSchedule().make_ddim(5)
     args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
     res = {}
-    for group in (0, 1):
-        monkeypatch.setenv('MKD_ENC_GROUP', str(group))
+    for group in (0, 1, 2):
+        monkeypatch.setenv('MKD_ENC_GROUP', str(group & 1))
+        monkeypatch.setenv('MKD_XCD_AUTO_RATIO', '0' if group == 2 else '2')          # (2: two chains, launch order everywhere)
         eng = MkdEngine(NetConfig())
         eng.init_random(0, norm_jitter=0.2)
         eng.prepare(hint, ctx)
@@ -314,5 +316,6 @@ def test_full_size_grouped_encoder_equals_two_chains_bit_for_bit(monkeypatch):
         res[group] = (e, lat, eng.step_launches())
         eng.close()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]), 'the XCD-aware tile order of the weight-heavy layers changed a bit'
     print(f'launches per step at batch 8: two chains {res[0][2]}, grouped {res[1][2]}')
     assert res[1][2] <= res[0][2] - 140
