@@ -57,12 +57,72 @@ def _csrc_sha16():
     return hashlib.sha256(src).hexdigest()[:16]
 
 
-def pmc_traffic_bytes_per_launch(kernel_fn):
-    """HBM-side bytes per launch of `kernel_fn` from the COMMITTED rocprofv3 --pmc summaries (profiles/, separate passes for
-    FETCH_SIZE and WRITE_SIZE): KB -> bytes, FETCH doubled for wide streaming reads on gfx950 (MI355X_MICROARCH.md §HBM).
-    (PMC cannot be collected from inside this process, so this number does not move between runs of one build: the second return
-    value says which files / commit it comes from and whether the kernel sources are still the ones that were profiled.)"""
+def live_pmc_passes(args):
+    """The HBM-side counters of THIS build on THIS box: two rocprofv3 child runs (one --pmc pass per counter, kernel trace only beside
+    it, as MI355X_MICROARCH.md §HBM prescribes) of a 2-step eager run of the same workload, reduced to
+    {kernel function: {'FETCH_SIZE': avg KB per launch, 'WRITE_SIZE': ..., 'dispatches': n}}.  Returns (dict | None, note).  Runs after
+    the timed region, rank 0, one GPU; every failure (no rocprofv3, a refused counter, a timeout) falls back to the committed summaries."""
     import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if not exe:
+        return None, 'rocprofv3 not on PATH'
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'MKD_DIST_BACKEND')}
+    env['TMPDIR'] = '/tmp'
+    work = ['--steps', '1', '--warmup', '0', '--ddim-steps', '2', '--no-cpu-baseline', '--graph', '0', '--decode', '0', '--live-pmc', '0',
+            '--batch', str(args.batch), '--res', str(args.res)] + (['--cfg'] if args.cfg else []) + (['--interp', str(args.interp)] if args.interp else [])
+    out = {}
+    base = tempfile.mkdtemp(prefix='mkd_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(base, counter)
+            cmd = [exe, '--kernel-trace', '--output-format', 'csv', '--pmc', counter, '-d', d, '-o', 'live', '--',
+                   sys.executable, os.path.abspath(__file__)] + work
+            t0 = time.perf_counter()
+            p = subprocess.Popen(cmd, env=env, cwd='/tmp', stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=float(os.environ.get('MKD_LIVE_PMC_TIMEOUT', '420')))
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)          # exactly the session started above
+                p.communicate()
+                return None, f'rocprofv3 --pmc {counter}: timed out'
+            found = glob.glob(os.path.join(d, '**', 'live_counter_collection.csv'), recursive=True)
+            if p.returncode != 0 or not found:
+                return None, f'rocprofv3 --pmc {counter}: rc {p.returncode}, {len(found)} counter file(s): {(err or "")[-300:]}'
+            tot = {}; ids = {}
+            for r in csv.DictReader(open(found[0])):
+                if r['Counter_Name'] != counter:
+                    continue
+                k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0]
+                tot[k] = tot.get(k, 0.0) + float(r['Counter_Value'])
+                ids.setdefault(k, set()).add(r['Dispatch_Id'])
+            for k in tot:
+                e = out.setdefault(k, {})
+                e[counter] = tot[k] / len(ids[k]); e['dispatches'] = len(ids[k])
+            log(f'live PMC pass {counter}: {len(tot)} kernels, {time.perf_counter() - t0:.0f} s')
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out, 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py ' + ' '.join(work)
+
+
+def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None):
+    """HBM-side bytes per launch of `kernel_fn`: FETCH_SIZE and WRITE_SIZE (KB -> bytes, FETCH doubled for wide streaming reads on gfx950,
+    MI355X_MICROARCH.md §HBM).  `live` (live_pmc_passes): measured by this run on this box.  Otherwise from the COMMITTED rocprofv3
+    summaries (profiles/), and the second return value says which files / commit they come from and whether the kernel sources are
+    still the ones that were profiled."""
+    import csv
+    if live:
+        n = 0; b = 0.0
+        for k, e in live.items():
+            if k.startswith(kernel_fn) and 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+                n += e['dispatches']; b += e['dispatches'] * (2.0 * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024.0
+        if n:
+            return b / n, {'collected_live': True, 'dispatches': n, 'command': live_note,
+                           'formula': '2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the launches of the kernel function'}
     for rnd in ('r3', 'r2'):
         tot = {}
         for name, mult in ((f'{rnd}_pmc_fetch_size_kb.csv', 2.0), (f'{rnd}_pmc_write_size_kb.csv', 1.0)):
@@ -81,7 +141,7 @@ def pmc_traffic_bytes_per_launch(kernel_fn):
             tot[name] = b / n
         if tot is None:
             continue
-        src = {'files': sorted('profiles/' + k for k in tot), 'collected_live': False}
+        src = {'files': sorted('profiles/' + k for k in tot), 'collected_live': False, 'live_attempt': live_note}
         prov = os.path.join(ROOT, 'profiles', f'{rnd}_provenance.json')
         if os.path.exists(prov):
             pv = json.load(open(prov))
@@ -198,6 +258,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=20, help='DDIM steps of the CPU baseline run (BASELINE config 1: 20; ~1.2 s each on 16 cores)')
     ap.add_argument('--graph', type=int, default=1, help='replay the DDIM step as a hipGraph (0 = eager launches)')
     ap.add_argument('--decode', type=int, default=1, help='1: VAE-decode the latents to images inside the timed step (images out)')
+    ap.add_argument('--live-pmc', type=int, default=1, help='1 (one GPU): after the timed region, two rocprofv3 --pmc child runs of a 2-step '
+                    'eager run measure FETCH_SIZE / WRITE_SIZE for roofline.traffic on this box; 0 / failure: the committed summaries')
     ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
     args = ap.parse_args()
 
@@ -307,7 +369,10 @@ def main():
         dom = max(agg, key=lambda f: agg[f]['ms'])
         d = agg[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes_per_launch(dom)
+        live, live_note = live_pmc_passes(args) if (args.live_pmc and world == 1) else (None, 'not attempted (--live-pmc 0 or more than one rank)')
+        if live is None:
+            log(f'live PMC: {live_note}; roofline.traffic from the committed summaries')
+        traffic, traffic_src = pmc_traffic_bytes_per_launch(dom, live, live_note)
         b2b_ms = sum(v['ms_b2b'] for k, v in prof.items() if fam[dom](k))
         roofline = {'bound': 'mfma', 'kernel': dom + ' (all tile configurations, one eps evaluation)', 'achieved': ach,
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
@@ -328,7 +393,7 @@ def main():
             hv = hb[hk]
             gbs = hv['bytes'] / (hv['ms'] * 1e-3) / 1e9
             gbs_b2b = hv['bytes'] / (hv['ms_b2b'] * 1e-3) / 1e9 if hv['ms_b2b'] > 0 else None
-            h_traffic, h_src = pmc_traffic_bytes_per_launch(hbm_fn[hk].split(' ')[0])
+            h_traffic, h_src = pmc_traffic_bytes_per_launch(tuple(hbm_fn[hk].split(' / ')), live, live_note)      # (every kernel function of the class)
             roofline_hbm = {'bound': 'hbm', 'kernel': f'{hbm_fn[hk]} ({hk} class, one eps evaluation)', 'achieved': gbs, 'peak': PEAK_HBM_GBS,
                             'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'traffic': h_traffic, 'traffic_source': h_src,
                             'launches_per_eval': hv['launches'], 'avg_launch_us': 1e3 * hv['ms'] / hv['launches'],

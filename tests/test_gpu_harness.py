@@ -127,10 +127,31 @@ def test_rccl_group_of_one_on_the_card():
     assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     env['MASTER_PORT'] = str(mdist.free_port())
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0', '--ddim-steps', '2',
-                        '--batch', '2', '--no-cpu-baseline'], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+                        '--batch', '2', '--no-cpu-baseline', '--live-pmc', '0'], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['backend'] == 'nccl' and out['ranks_seen'] == 1 and out['n_gpus'] == 1 and out['rehearsal_single_device'] is False
-    assert out['value'] > 0
+    assert out['value'] > 0 and out['roofline']['traffic_source']['collected_live'] is False
+
+
+def test_bench_measures_its_hbm_counters_live():
+    """`roofline.traffic` / `roofline_hbm.traffic` of the bench line are measured BY the bench run when rocprofv3 is there: two --pmc child
+    passes (FETCH_SIZE, WRITE_SIZE) of a 2-step eager run of the same workload, after the timed region.  The GroupNorm class moves at
+    least its algorithmic bytes and not more than a few times that."""
+    import json
+    import shutil
+    if not shutil.which('rocprofv3'):
+        pytest.skip('rocprofv3 not installed')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--ddim-steps', '2', '--batch', '2',
+                        '--no-cpu-baseline', '--decode', '0'], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    for key in ('roofline', 'roofline_hbm'):
+        src = out[key]['traffic_source']
+        assert src['collected_live'] is True and src['dispatches'] > 0, (key, src, r.stderr[-3000:])
+        assert out[key]['traffic'] > 0
+    h = out['roofline_hbm']
+    assert 0.2 * h["bytes_per_launch"] < h["traffic"] < 8 * h["bytes_per_launch"], h
