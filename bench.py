@@ -288,7 +288,7 @@ def main():
     eng = MkdEngine(cfg, dev)
     if args.decode:
         eng.configure_vae(VaeConfig())
-    want_cpu = rank == 0 and not args.no_cpu_baseline
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline      # (the CPU baseline is timed at N = 1 only)
     log(f'rank {rank}/{world}: generating 1.22 G synthetic weights on {dev}')
     sd_cpu = gen_weights(eng, seed=0, keep_cpu=want_cpu)
     log('weights loaded')
