@@ -258,10 +258,14 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=20, help='DDIM steps of the CPU baseline run (BASELINE config 1: 20; ~1.2 s each on 16 cores)')
     ap.add_argument('--graph', type=int, default=1, help='replay the DDIM step as a hipGraph (0 = eager launches)')
     ap.add_argument('--decode', type=int, default=1, help='1: VAE-decode the latents to images inside the timed step (images out)')
-    ap.add_argument('--live-pmc', type=int, default=1, help='1 (one GPU): after the timed region, two rocprofv3 --pmc child runs of a 2-step '
-                    'eager run measure FETCH_SIZE / WRITE_SIZE for roofline.traffic on this box; 0 / failure: the committed summaries')
+    ap.add_argument('--live-pmc', type=int, default=-1, help='1 (one GPU): after the timed region, two rocprofv3 --pmc child runs of a 2-step '
+                    'eager run measure FETCH_SIZE / WRITE_SIZE for roofline.traffic on this box; 0 / failure: the committed summaries; '
+                    '-1 (default): on for the full run (CPU baseline on, not itself under a profiler), off for --no-cpu-baseline experiment runs')
     ap.add_argument('--ops-csv', default=None, help='write per-launch-group device times of one eps evaluation')
     args = ap.parse_args()
+    if args.live_pmc < 0:
+        profiled = any(k.startswith('ROCPROF') for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+        args.live_pmc = int(not args.no_cpu_baseline and not profiled)
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # self-launch: nothing in this process has touched the GPU (device_count() does not initialise HIP on this image)

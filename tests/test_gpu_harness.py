@@ -146,7 +146,7 @@ def test_bench_measures_its_hbm_counters_live():
         pytest.skip('rocprofv3 not installed')
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--ddim-steps', '2', '--batch', '2',
-                        '--no-cpu-baseline', '--decode', '0'], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+                        '--no-cpu-baseline', '--decode', '0', '--live-pmc', '1'], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     for key in ('roofline', 'roofline_hbm'):
