@@ -85,7 +85,7 @@ def live_pmc_passes(args):
             t0 = time.perf_counter()
             p = subprocess.Popen(cmd, env=env, cwd='/tmp', stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
-                _, err = p.communicate(timeout=float(os.environ.get('MKD_LIVE_PMC_TIMEOUT', '420')))
+                _, err = p.communicate(timeout=float(os.environ.get('MKD_LIVE_PMC_TIMEOUT', '90')))
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)          # exactly the session started above
                 p.communicate()
