@@ -254,6 +254,24 @@ int mkd_gemm_groupnorm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
                             int conv3x3, int batch, int Hin, int Win, int Cin, int Hout, int Wout,
                             int stride, int upsample, int splitk, int rows_per_sample,
                             const float* gamma, const float* beta, float eps, int silu, uint16_t* y, int ld_y, void* stream);
+/* ---- fused row-local tail of a SpatialTransformer block (kernels_tfm.hip), stand-alone form ---------------------------------
+ * UPSTREAM cldm BasicTransformerBlock after the self-attention product, reached from diffmk/makeup_diffuse.py:164-168:
+ *   h1 = attn1.to_out(a1) + h0;  h2 = attn2.to_out(softmax(attn2.to_q(LN2 h1) K^T dh^-0.5) V) + h1;
+ *   out = proj_out(ff.net.2(GEGLU(ff.net.0.proj(LN3 h2))) + h2) + x_in
+ * as ONE kernel per 64-token row tile (d = 320, 8 heads).  mkd_tfm_tail_create takes the block's fp32 DEVICE weights under their
+ * upstream shapes ([d,d], [8d,d], [d,4d], vectors) and builds the packed operand-order copies; mkd_tfm_tail_set_context packs the
+ * cross-attention K | V projections of the context (kv: [batch * Tk, 2d] bf16, K in columns [0,d), V in [d,2d); Tk <= 80);
+ * mkd_tfm_tail_run: a1, h0, x_in, out are [M, d] bf16 with row strides, M = samples * T, T a multiple of 64.  The engine uses the
+ * same kernel inside mkd_eps for its d = 320 blocks (mkd_set_option "tfm_tail"). */
+typedef struct mkd_tfm_tail mkd_tfm_tail;
+int  mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, const float* norm2_g, const float* norm2_b,
+                         const float* to_q2_w, const float* to_out2_w, const float* to_out2_b, const float* norm3_g, const float* norm3_b,
+                         const float* ff0_w, const float* ff0_b, const float* ff2_w, const float* ff2_b, const float* proj_out_w,
+                         const float* proj_out_b, mkd_tfm_tail** out);
+void mkd_tfm_tail_destroy(mkd_tfm_tail* h);
+int  mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream);
+int  mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_t* h0, int ldh, const uint16_t* xin, int ldx,
+                      uint16_t* out, int ldo, int M, int T, void* stream);
 /* LayerNorm over the last dim of [rows, d] bf16. */
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
                   uint16_t* y, int rows, int d, void* stream);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmkd.so')
-SOURCES = ['kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_misc.hip', 'engine.hip']
+SOURCES = ['kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_tfm.hip', 'kernels_misc.hip', 'engine.hip']
 HEADERS = ['mkd_common.h', 'gemm_device.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'mkd.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result',
          '-ffp-contract=fast']

@@ -2586,4 +2586,60 @@ int mkd_pack_conv_weight(const float* w, uint16_t* out, int Cout, int Cin, int k
     return launch_pack_conv_weight(w, out, Cout, Cin, kh, kw, (hipStream_t)stream);
 }
 
+// ---- fused transformer tail, stand-alone (unit parity test, tools/bench_tfm_tail.py) ------------------------------------------
+struct mkd_tfm_tail { int d = 0; bf16_t* wpk = nullptr; float* vec = nullptr; bf16_t* kvp = nullptr; int kv_batch = 0, Tk = 0; std::vector<void*> owned; };
+void mkd_tfm_tail_destroy(mkd_tfm_tail* h) {
+    if (!h) return;
+    for (void* p : h->owned) hipFree(p);
+    delete h;
+}
+int mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, const float* norm2_g, const float* norm2_b,
+                        const float* to_q2_w, const float* to_out2_w, const float* to_out2_b, const float* norm3_g, const float* norm3_b,
+                        const float* ff0_w, const float* ff0_b, const float* ff2_w, const float* ff2_b, const float* proj_out_w,
+                        const float* proj_out_b, mkd_tfm_tail** out) {
+    if (!out) return mkd_fail(MKD_ERR_ARG, "null out");
+    if (!tfm_tail_weight_bytes(d)) return mkd_fail(MKD_ERR_UNSUPPORTED, "tfm_tail: only d = 320 is built");
+    mkd_tfm_tail* h = new mkd_tfm_tail; h->d = d;
+    auto dal = [&](size_t bytes, void** o) -> int { MKD_HIP_CHECK(hipMalloc(o, bytes)); h->owned.push_back(*o); return 0; };
+    void *wo1 = nullptr, *wq = nullptr, *sq = nullptr, *bq = nullptr, *wo2 = nullptr, *wg = nullptr, *sg = nullptr, *bg = nullptr, *wm = nullptr, *bm = nullptr;
+    const size_t dd = (size_t)d * d;
+    int rc = dal(dd * 2, &wo1);
+    if (!rc) rc = dal(dd * 2, &wq); if (!rc) rc = dal(d * 4, &sq); if (!rc) rc = dal(d * 4, &bq);
+    if (!rc) rc = dal(dd * 2, &wo2);
+    if (!rc) rc = dal(8 * dd * 2, &wg); if (!rc) rc = dal(8 * d * 4, &sg); if (!rc) rc = dal(8 * d * 4, &bg);
+    if (!rc) rc = dal(5 * dd * 2, &wm); if (!rc) rc = dal(d * 4, &bm);
+    if (!rc) rc = dal(tfm_tail_weight_bytes(d), (void**)&h->wpk);
+    if (!rc) rc = dal(tfm_tail_vec_bytes(d), (void**)&h->vec);
+    if (!rc) rc = launch_f32_to_bf16(to_out1_w, (bf16_t*)wo1, (int64_t)dd, 0);
+    if (!rc) rc = launch_f32_to_bf16(to_out2_w, (bf16_t*)wo2, (int64_t)dd, 0);
+    if (!rc) rc = launch_fold_layernorm(to_q2_w, norm2_g, norm2_b, nullptr, d, d, (bf16_t*)wq, 0, 1, (float*)sq, (float*)bq, 0);
+    for (int half = 0; half < 2 && !rc; ++half)      // rows [0, 4d) value, [4d, 8d) gate -> row 2 j = value_j, 2 j + 1 = gate_j (as mkd_ctx::finalize)
+        rc = launch_fold_layernorm(ff0_w + (size_t)half * 4 * dd, norm3_g, norm3_b, ff0_b + half * 4 * d, 4 * d, d, (bf16_t*)wg, half, 2, (float*)sg, (float*)bg, 0);
+    if (!rc) rc = launch_merge_ff_out(proj_out_w, ff2_w, ff2_b, proj_out_b, (bf16_t*)wm, (float*)bm, d, 0);
+    if (!rc) {
+        TfmTailWeights s{(const bf16_t*)wo1, to_out1_b, (const bf16_t*)wq, (const float*)sq, (const float*)bq, (const bf16_t*)wo2, to_out2_b,
+                         (const bf16_t*)wg, (const float*)sg, (const float*)bg, (const bf16_t*)wm, (const float*)bm};
+        rc = tfm_tail_pack_weights(d, s, h->wpk, h->vec, 0);
+    }
+    if (rc) { mkd_tfm_tail_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+int mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream) {
+    if (!h) return mkd_fail(MKD_ERR_ARG, "null handle");
+    if (batch > h->kv_batch) {
+        void* p = nullptr;
+        MKD_HIP_CHECK(hipMalloc(&p, tfm_tail_kv_bytes(h->d, batch)));
+        h->owned.push_back(p); h->kvp = (bf16_t*)p; h->kv_batch = batch;
+    }
+    h->Tk = Tk;
+    return launch_tfm_tail_pack_kv(h->d, kv, ldkv, batch, Tk, h->kvp, (hipStream_t)stream);
+}
+int mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_t* h0, int ldh, const uint16_t* xin, int ldx, uint16_t* out,
+                     int ldo, int M, int T, void* stream) {
+    if (!h || !h->kvp) return mkd_fail(MKD_ERR_STATE, "tfm_tail: set the context first");
+    if (T <= 0 || M % T || M / T > h->kv_batch) return mkd_fail(MKD_ERR_ARG, "tfm_tail: M must be samples x T within the packed context");
+    return launch_tfm_tail(h->d, h->wpk, h->vec, a1, lda, h0, ldh, xin, ldx, h->kvp, out, ldo, M, T, h->Tk, (hipStream_t)stream);
+}
+
 }  // extern "C"

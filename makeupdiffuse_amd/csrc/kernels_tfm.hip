@@ -1,0 +1,569 @@
+// Row-local tail of a SpatialTransformer block as ONE kernel (gfx950).
+//
+// After self-attention every op of cldm's BasicTransformerBlock / SpatialTransformer (the two net calls it serves
+// are /root/reference/diffmk/makeup_diffuse.py:164-168, sizes from /root/reference/diffmodels/base_diffusion_makeup.yaml:52-84) is
+// per token:
+//     h1  = attn1.to_out(a1) + h0                       a1 = softmax(q k^T) v of the self-attention (its own kernel), h0 = proj_in(norm(x))
+//     q   = attn2.to_q(LN2(h1));  a2 = softmax(q K^T * dh^-0.5) V over the 77 cached context rows;  h2 = attn2.to_out(a2) + h1
+//     gg  = GEGLU(ff.net.0.proj(LN3(h2)));  out = proj_out(ff.net.2(gg) + h2) + x_in
+// The engine runs this as 7 dependent launches with 6 activation round trips.  Here a workgroup of 8 waves owns
+// 64 consecutive tokens of one sample and keeps them in LDS across all five GEMMs:
+//   * every product is computed TRANSPOSED, out^T[n][m] = sum_k W[n][k] X[m][k] with v_mfma_f32_16x16x32_bf16: W fragments are the
+//     A operand, the 64-token activation tile the B operand.  The waves split the OUTPUT CHANNELS only, so a weight fragment is
+//     needed by exactly one wave: it goes from L2 straight into that wave's registers, 1 KiB contiguous per wave-instruction
+//     (weights are re-packed once at load time in exactly the order a wave consumes them), TFM_PD k-steps ahead; only activations
+//     live in LDS;
+//   * activations sit in LDS in MFMA-operand order, tile[16-row fragment][32-wide k-step][lane][8]: a B fragment is ONE lane-linear
+//     ds_read_b128 (conflict-free), and an epilogue lane (4 consecutive channels of one token) stores ONE 8-byte word;
+//   * LayerNorm 2 / 3 are folded into the consumer's weights (W' = W diag(gamma), s = rowsum(W'), b' = b + W beta: the same folded
+//     tensors the engine's LayerNorm-on-the-fly GEMM uses) and the epilogue applies rstd (acc - mean s) + b'; the row statistics are
+//     taken from the bf16-rounded values the producing epilogue holds (per-wave partials in LDS, summed in fixed order:
+//     bit-repeatable);
+//   * the 8d-wide GEGLU intermediate is produced in 256-column chunks into a double-buffered LDS tile and consumed chunk by chunk
+//     by the [ff.net.2 . proj_out | proj_out] accumulator (the merged K = 5d weight of DESIGN.md §4.2): it never exists in memory;
+//   * cross-attention: wave = head.  K and V of the (sample, head) come pre-packed in MFMA-operand order (built once per
+//     mkd_prepare beside the K/V cache: the context is constant over the steps), scores are computed transposed so a lane owns
+//     one query, P feeds P.V from the accumulator registers (k order permuted identically in the packed V).
+// Per workgroup: 3.3 MB of weights (d = 320) streamed once from L2, 13.4 K MFMAs; HBM sees the a1 / h0 / x_in tiles in and the
+// block output out.
+#include "mkd_common.h"
+#include <vector>
+
+namespace {
+
+constexpr int TFM_NW = 8;            // waves per workgroup (= attention heads)
+constexpr int TFM_TM = 64;           // tokens per workgroup
+constexpr int TFM_MF = TFM_TM / 16;  // 16-token B fragments
+constexpr int TFM_CH = 256;          // GEGLU output columns per chunk
+constexpr int TFM_GKS = TFM_CH / 32; // k-steps of one chunk in the merged FF GEMM
+constexpr int TFM_PD = 3;            // weight k-steps in flight per wave
+constexpr int TFM_KF = 5;            // 16-key fragments of the context (<= 80 keys)
+constexpr int TFM_PVS = 3;           // 32-key steps of P.V (96 >= 80)
+
+template <int D>
+struct TfmCfg {
+    static constexpr int HEADS = TFM_NW, DH = D / HEADS;
+    static constexpr int KSD = D / 32;                    // k-steps over D
+    static constexpr int NFR = D / 16;                    // W fragments (16 output channels) of an N = D product
+    static constexpr int NFB = NFR / TFM_NW;              // fragments per wave: the first NWA waves take NFA = NFB + 1
+    static constexpr int NWA = NFR - NFB * TFM_NW;
+    static constexpr int NFA = NWA ? NFB + 1 : NFB;
+    static constexpr int NCH = 4 * D / TFM_CH;            // GEGLU chunks
+    static constexpr int KSM = 5 * D / 32;                // k-steps of the merged FF GEMM
+    static constexpr int KSQ = (DH + 31) / 32;            // k-steps of q K^T (head dim zero-padded in the packs)
+    static constexpr int MD = (DH + 15) / 16;             // O^T fragments
+    static constexpr int KV_UNITS = TFM_KF * KSQ + MD * TFM_PVS;      // 1 KiB units per (sample, head)
+    // packed weight offsets, in 1 KiB units (64 lanes x 8 bf16)
+    static constexpr int OFF_O1 = 0, OFF_Q = NFR * KSD, OFF_O2 = 2 * NFR * KSD, OFF_G = 3 * NFR * KSD;
+    static constexpr int OFF_M = OFF_G + NCH * 4 * TFM_NW * KSD, UNITS = OFF_M + NFR * KSM;
+    // packed vectors (floats)
+    static constexpr int V_BO1 = 0, V_SQ = D, V_BQ = 2 * D, V_BO2 = 3 * D, V_SV = 4 * D, V_BV = 8 * D, V_SG = 12 * D, V_BG = 16 * D,
+                         V_BM = 20 * D, V_TOTAL = 21 * D;
+    static constexpr int BUF = TFM_TM * D * 2;            // one activation tile in LDS
+    static constexpr int GBUF = TFM_MF * TFM_GKS * 1024;
+    static constexpr int LDS = 2 * BUF + GBUF + 2 * TFM_NW * TFM_TM * 8;
+    static_assert(D % 64 == 0 && DH % 8 == 0 && (4 * D) % TFM_CH == 0 && GBUF <= BUF, "tile geometry");
+};
+
+struct TfmTailArgs {
+    const bf16x8* wpk;          // packed weights (TfmCfg::UNITS KiB)
+    const float* vec;           // packed bias / LayerNorm-correction vectors
+    const bf16_t* a1; int lda;  // self-attention output [M, d]
+    const bf16_t* h0; int ldh;  // residual of attn1.to_out
+    const bf16_t* xin; int ldx; // the SpatialTransformer's input (residual of proj_out)
+    const bf16x8* kvp;          // packed context K / V: [sample][head][KV_UNITS] KiB
+    bf16_t* out; int ldo;
+    int T;                      // tokens per sample (multiple of TFM_TM)
+    int Tk;                     // context keys (<= 16 * TFM_KF)
+    float scale_log2e;          // dh^-0.5 * log2(e)
+};
+
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+
+// byte offset of the 16-byte chunk (token row, 8-channel group c) inside a tile with KS k-steps per row fragment
+__device__ __forceinline__ int lds_chunk(int mf, int c, int r, int KS) { return (((mf * KS + (c >> 2)) << 6) + ((c & 3) << 4) + r) << 4; }
+
+// acc[f][mf] += W fragment (f, ks) x activation fragment (mf, ks) over KS k-steps.  wp: the wave's packed stream, unit order
+// [ks][f], already offset by the lane; xb: LDS tile + lane * 16 (+ first k-step * 1024); xs: bytes between row fragments.
+template <int NF, int KS>
+__device__ __forceinline__ void stage_mm(const bf16x8* __restrict__ wp, const char* xb, int xs, f32x4 (&acc)[NF][TFM_MF]) {
+    bf16x8 wr[TFM_PD][NF];
+#pragma unroll
+    for (int p = 0; p < TFM_PD; ++p)
+        if (p < KS) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) wr[p][f] = wp[(p * NF + f) * 64];
+        }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 xf[TFM_MF];
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) xf[mf] = *(const bf16x8*)(xb + mf * xs + ks * 1024);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf)
+                acc[f][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ks % TFM_PD][f], xf[mf], acc[f][mf], 0, 0, 0);
+        if (ks + TFM_PD < KS) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) wr[ks % TFM_PD][f] = wp[((ks + TFM_PD) * NF + f) * 64];
+        }
+    }
+}
+
+template <int NF>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NF][TFM_MF]) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) acc[f][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// row statistics of the tile a stage wrote: this wave's partial (sum, sum of squares) per token -> st[wave][token]
+__device__ __forceinline__ void put_stats(float (&s)[TFM_MF], float (&q)[TFM_MF], float2* st, int w, int r, int g) {
+#pragma unroll
+    for (int mf = 0; mf < TFM_MF; ++mf) {
+        float a = s[mf], b = q[mf];
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        if (g == 0) st[w * TFM_TM + 16 * mf + r] = make_float2(a, b);
+    }
+}
+template <int D>
+__device__ __forceinline__ void get_stats(const float2* st, int r, float (&mean)[TFM_MF], float (&rstd)[TFM_MF]) {
+#pragma unroll
+    for (int mf = 0; mf < TFM_MF; ++mf) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < TFM_NW; ++w) { const float2 v = st[w * TFM_TM + 16 * mf + r]; a += v.x; b += v.y; }      // fixed order
+        const float m = a * (1.0f / D);
+        const float var = fmaxf(b * (1.0f / D) - m * m, 0.f);
+        mean[mf] = m;
+        rstd[mf] = __builtin_amdgcn_rsqf(var + 1e-5f);
+    }
+}
+
+// the program of one wave; NFN = its share of the 16-channel fragments of an N = D product, fr0 = the first of them
+template <int D, int NFN>
+__device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const int w, const int lane, const int fr0) {
+    using C = TfmCfg<D>;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * TFM_TM;
+    char* const bufA = smem;
+    char* const bufB = smem + C::BUF;
+    char* const bufG1 = smem + 2 * C::BUF;
+    float2* const st1 = (float2*)(smem + 2 * C::BUF + C::GBUF);
+    float2* const st2 = st1 + TFM_NW * TFM_TM;
+    const bf16x8* const wp = a.wpk + lane;
+    const float* const vec = a.vec;
+    const int xs = C::KSD * 1024;
+
+    // address pieces of this lane's epilogue word: fragment fr -> channels 16 fr + 4 g .. + 3 of token 16 mf + r
+    auto out_off = [&](int mf, int fr) { return lds_chunk(mf, 2 * fr + (g >> 1), r, C::KSD) + (g & 1) * 8; };
+
+    // ---- S1: h1 = attn1.to_out(a1) + h0 -> bufB, row statistics -> st1 -------------------------------------------------
+    {
+        U16x4 res[NFN][TFM_MF];
+#pragma unroll
+        for (int f = 0; f < NFN; ++f)
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf)
+                res[f][mf] = *(const U16x4*)(a.h0 + (size_t)(row0 + 16 * mf + r) * a.ldh + 16 * (fr0 + f) + 4 * g);
+        f32x4 acc[NFN][TFM_MF];
+        zero_acc<NFN>(acc);
+        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O1 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        float s[TFM_MF], q[TFM_MF];
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < NFN; ++f) {
+            const float4 bb = *(const float4*)(vec + C::V_BO1 + 16 * (fr0 + f) + 4 * g);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf) {
+                U16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o.v[i] = f32_to_bf16(acc[f][mf][i] + bv[i] + bf16_to_f32(res[f][mf].v[i]));
+                    const float vr = bf16_to_f32(o.v[i]);
+                    s[mf] += vr; q[mf] += vr * vr;
+                }
+                *(U16x4*)(bufB + out_off(mf, fr0 + f)) = o;
+            }
+        }
+        put_stats(s, q, st1, w, r, g);
+    }
+    __syncthreads();
+
+    // ---- S2: q = attn2.to_q(LN2(h1)) -> bufA (a1 is dead) --------------------------------------------------------------
+    {
+        float mean[TFM_MF], rstd[TFM_MF];
+        get_stats<D>(st1, r, mean, rstd);
+        f32x4 acc[NFN][TFM_MF];
+        zero_acc<NFN>(acc);
+        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_Q + C::KSD * fr0) * 64, bufB + lane * 16, xs, acc);
+#pragma unroll
+        for (int f = 0; f < NFN; ++f) {
+            const float4 ss = *(const float4*)(vec + C::V_SQ + 16 * (fr0 + f) + 4 * g);
+            const float4 bb = *(const float4*)(vec + C::V_BQ + 16 * (fr0 + f) + 4 * g);
+            const float sv[4] = {ss.x, ss.y, ss.z, ss.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf) {
+                U16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o.v[i] = f32_to_bf16(rstd[mf] * (acc[f][mf][i] - mean[mf] * sv[i]) + bv[i]);
+                *(U16x4*)(bufA + out_off(mf, fr0 + f)) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S3: cross-attention over the cached context, wave = head; a2 overwrites q in place --------------------------
+    {
+        const int b = row0 / a.T;
+        const bf16x8* kv = a.kvp + ((size_t)(b * C::HEADS + w) * C::KV_UNITS) * 64 + lane;
+        bf16x8 kf[TFM_KF][C::KSQ], vf[C::MD][TFM_PVS];
+#pragma unroll
+        for (int i = 0; i < TFM_KF; ++i)
+#pragma unroll
+            for (int ks = 0; ks < C::KSQ; ++ks) kf[i][ks] = kv[(i * C::KSQ + ks) * 64];
+#pragma unroll
+        for (int md = 0; md < C::MD; ++md)
+#pragma unroll
+            for (int s = 0; s < TFM_PVS; ++s) vf[md][s] = kv[(TFM_KF * C::KSQ + md * TFM_PVS + s) * 64];
+        const int c0 = (C::DH / 8) * w;                 // first 8-channel group of this head
+#pragma unroll 1
+        for (int qf = 0; qf < TFM_MF; ++qf) {
+            // Q fragment (B operand): lane holds q[16 qf + r][DH w + 32 ks + 8 g + j]; channels past the head are zero
+            bf16x8 qv[C::KSQ];
+#pragma unroll
+            for (int ks = 0; ks < C::KSQ; ++ks) {
+                const bool ok = 32 * ks + 8 * g < C::DH;
+                const bf16x8 t = *(const bf16x8*)(bufA + lds_chunk(qf, ok ? c0 + 4 * ks + g : c0, r, C::KSD));
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                qv[ks] = ok ? t : z;
+            }
+            f32x4 stt[TFM_KF + 1];
+#pragma unroll
+            for (int i = 0; i < TFM_KF; ++i) {
+                stt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < C::KSQ; ++ks) stt[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][ks], qv[ks], stt[i], 0, 0, 0);
+            }
+            stt[TFM_KF] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // lane holds raw scores of query r for keys 16 i + 4 g + j
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TFM_KF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sc = (16 * i + 4 * g + j < a.Tk) ? stt[i][j] : -INFINITY;
+                    stt[i][j] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m = mx * a.scale_log2e;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TFM_KF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(stt[i][j], a.scale_log2e, -m));
+                    stt[i][j] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(psum);
+            // O^T[d][q] = V^T[d][key'] P^T[key'][q]; key'(g, j) = 32 s + (j < 4 ? 4 g + j : 16 + 4 g + j - 4): the packed V uses the same order
+            f32x4 oacc[C::MD];
+#pragma unroll
+            for (int md = 0; md < C::MD; ++md) oacc[md] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < TFM_PVS; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (__bf16)stt[2 * s][j];
+                    pf[4 + j] = (__bf16)stt[2 * s + 1][j];
+                }
+#pragma unroll
+                for (int md = 0; md < C::MD; ++md) oacc[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[md][s], pf, oacc[md], 0, 0, 0);
+            }
+#pragma unroll
+            for (int md = 0; md < C::MD; ++md) {
+                const int dc = 16 * md + 4 * g;
+                if (dc < C::DH) {
+                    U16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o.v[i] = f32_to_bf16(oacc[md][i] * inv);
+                    const int n = C::DH * w + dc;
+                    *(U16x4*)(bufA + lds_chunk(qf, n >> 3, r, C::KSD) + (n & 7) * 2) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S4: h2 = attn2.to_out(a2) + h1 -> bufB in place, row statistics -> st2 ----------------------------------------
+    {
+        f32x4 acc[NFN][TFM_MF];
+        zero_acc<NFN>(acc);
+        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O2 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        float s[TFM_MF], q[TFM_MF];
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < NFN; ++f) {
+            const float4 bb = *(const float4*)(vec + C::V_BO2 + 16 * (fr0 + f) + 4 * g);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf) {
+                char* const p = bufB + out_off(mf, fr0 + f);
+                const U16x4 h1 = *(const U16x4*)p;
+                U16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o.v[i] = f32_to_bf16(acc[f][mf][i] + bv[i] + bf16_to_f32(h1.v[i]));
+                    const float vr = bf16_to_f32(o.v[i]);
+                    s[mf] += vr; q[mf] += vr * vr;
+                }
+                *(U16x4*)p = o;
+            }
+        }
+        put_stats(s, q, st2, w, r, g);
+    }
+    __syncthreads();
+
+    // ---- S5 / S6: GEGLU chunks -> double-buffered LDS tile -> merged [ff.net.2 . proj_out | proj_out] accumulator -----------
+    f32x4 accF[NFN][TFM_MF];
+    zero_acc<NFN>(accF);
+    {
+        float mean[TFM_MF], rstd[TFM_MF];
+        get_stats<D>(st2, r, mean, rstd);
+        const bf16x8* const wm = wp + (size_t)(C::OFF_M + C::KSM * fr0) * 64;
+#pragma unroll 1
+        for (int c = 0; c < C::NCH; ++c) {
+            char* const G = (c & 1) ? bufG1 : bufA;
+            {
+                f32x4 acc[4][TFM_MF];
+                zero_acc<4>(acc);
+                stage_mm<4, C::KSD>(wp + (size_t)(C::OFF_G + (c * TFM_NW + w) * 4 * C::KSD) * 64, bufB + lane * 16, xs, acc);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int col = 16 * (2 * w + p) + 4 * g;           // column inside the chunk
+                    const int j0 = TFM_CH * c + col;                    // GEGLU output column
+                    const float4 sv4 = *(const float4*)(vec + C::V_SV + j0), bv4 = *(const float4*)(vec + C::V_BV + j0);
+                    const float4 sg4 = *(const float4*)(vec + C::V_SG + j0), bg4 = *(const float4*)(vec + C::V_BG + j0);
+                    const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+                    const float sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w}, bg[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
+#pragma unroll
+                    for (int mf = 0; mf < TFM_MF; ++mf) {
+                        U16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float uv = rstd[mf] * (acc[2 * p][mf][i] - mean[mf] * sv[i]) + bv[i];
+                            const float ug = rstd[mf] * (acc[2 * p + 1][mf][i] - mean[mf] * sg[i]) + bg[i];
+                            o.v[i] = f32_to_bf16(uv * gelu_erf_f(ug));
+                        }
+                        *(U16x4*)(G + lds_chunk(mf, col >> 3, r, TFM_GKS) + (col & 7) * 2) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            stage_mm<NFN, TFM_GKS>(wm + (size_t)(c * TFM_GKS * NFN) * 64, G + lane * 16, TFM_GKS * 1024, accF);
+        }
+        // the h2 part of the merged GEMM (K columns 4d .. 5d)
+        stage_mm<NFN, C::KSD>(wm + (size_t)(C::NCH * TFM_GKS * NFN) * 64, bufB + lane * 16, xs, accF);
+    }
+
+    // ---- out = accF + (proj_out . b2 + b_proj_out) + x_in ----------------------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < NFN; ++f) {
+        const int n = 16 * (fr0 + f) + 4 * g;
+        const float4 bb = *(const float4*)(vec + C::V_BM + n);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) {
+            const size_t row = (size_t)(row0 + 16 * mf + r);
+            const U16x4 xr = *(const U16x4*)(a.xin + row * a.ldx + n);
+            U16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = f32_to_bf16(accF[f][mf][i] + bv[i] + bf16_to_f32(xr.v[i]));
+            *(U16x4*)(a.out + row * a.ldo + n) = o;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs a) {
+    using C = TfmCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // a1 tile -> bufA in operand order: 1 KiB block (mf, ks) = 64 lanes x 16 B, lane (g, r) holds a1[16 mf + r][32 ks + 8 g ..]
+    {
+        const int row0 = blockIdx.x * TFM_TM;
+        constexpr int PER = TFM_MF * C::KSD / TFM_NW;
+        static_assert(TFM_MF * C::KSD % TFM_NW == 0, "a1 tile blocks per wave");
+        U16x8 t[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int blk = w + i * TFM_NW, mf = blk / C::KSD, ks = blk - mf * C::KSD;
+            t[i] = *(const U16x8*)(a.a1 + (size_t)(row0 + 16 * mf + (lane & 15)) * a.lda + 32 * ks + 8 * (lane >> 4));
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) *(U16x8*)(smem + ((w + i * TFM_NW) * 64 + lane) * 16) = t[i];
+    }
+    __syncthreads();
+    if (C::NWA == TFM_NW || w < C::NWA) tfm_wave<D, C::NFA>(a, smem, w, lane, w * C::NFA);
+    else tfm_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
+}
+
+// ---- packing ---------------------------------------------------------------------------------------------------------------
+// one 1 KiB unit per block: out[u][lane][j] = W[rows[u][lane & 15]][32 ks[u] + 8 (lane >> 4) + j]
+__global__ void tfm_pack_units_kernel(const bf16_t* __restrict__ W, int ldw, const int* __restrict__ tab, bf16_t* __restrict__ out) {
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const int* t = tab + (size_t)u * 17;
+    const int row = t[lane & 15], ks = t[16];
+    *(U16x8*)(out + ((size_t)u * 64 + lane) * 8) = *(const U16x8*)(W + (size_t)row * ldw + 32 * ks + 8 * (lane >> 4));
+}
+
+// context K / V of one (sample, head) in operand order, zero padded: kv [B * Tk, 2 d] (K | V), heads of dh channels
+template <int D>
+__global__ void tfm_pack_kv_kernel(const bf16_t* __restrict__ kv, int ldkv, int Tk, bf16_t* __restrict__ out) {
+    using C = TfmCfg<D>;
+    const int bh = blockIdx.x, b = bh / C::HEADS, h = bh - b * C::HEADS;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const bf16_t* base = kv + (size_t)b * Tk * ldkv + h * C::DH;
+    bf16_t* o = out + (size_t)bh * C::KV_UNITS * 512;
+    for (int u = threadIdx.x >> 6; u < C::KV_UNITS; u += blockDim.x >> 6) {
+        U16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v.v[j] = 0;
+        if (u < TFM_KF * C::KSQ) {                       // K fragment (key block i, k-step ks): K[16 i + r][32 ks + 8 g + j]
+            const int i = u / C::KSQ, ks = u - i * C::KSQ;
+            const int key = 16 * i + r, d0 = 32 * ks + 8 * g;
+            if (key < Tk && d0 < C::DH) v = *(const U16x8*)(base + (size_t)key * ldkv + d0);
+        } else {                                         // V^T fragment (channel block md, key step s): V[key'(g, j)][16 md + r]
+            const int uu = u - TFM_KF * C::KSQ, md = uu / TFM_PVS, s = uu - md * TFM_PVS;
+            const int dch = 16 * md + r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+                if (key < Tk && dch < C::DH) v.v[j] = base[(size_t)key * ldkv + D + dch];
+            }
+        }
+        *(U16x8*)(o + ((size_t)u * 64 + lane) * 8) = v;
+    }
+}
+
+template <int D>
+int pack_stage(const bf16_t* W, int ldw, const std::vector<int>& tab, bf16_t* out_units, hipStream_t stream, std::vector<void*>& tmp) {
+    const int n = (int)(tab.size() / 17);
+    int* d = nullptr;
+    MKD_HIP_CHECK(hipMalloc((void**)&d, tab.size() * sizeof(int)));
+    tmp.push_back(d);
+    MKD_HIP_CHECK(hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(tfm_pack_units_kernel, dim3(n), dim3(64), 0, stream, W, ldw, d, out_units);
+    MKD_LAUNCH_CHECK("tfm_pack_units_kernel");
+    return 0;
+}
+
+template <int D>
+int pack_weights_t(const TfmTailWeights& s, bf16_t* wpk, float* vec, hipStream_t stream) {
+    using C = TfmCfg<D>;
+    std::vector<void*> tmp;
+    auto first_frag = [](int w) { return w < C::NWA ? w * C::NFA : C::NWA * C::NFA + (w - C::NWA) * C::NFB; };
+    auto nfrag = [](int w) { return w < C::NWA ? C::NFA : C::NFB; };
+    // an N = D product with KS k-steps: wave streams one after the other, unit order [ks][f]; fragment fr = rows 16 fr .. + 15
+    auto plain = [&](int KS) {
+        std::vector<int> tab;
+        for (int w = 0; w < TFM_NW; ++w)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int f = 0; f < nfrag(w); ++f) {
+                    for (int i = 0; i < 16; ++i) tab.push_back(16 * (first_frag(w) + f) + i);
+                    tab.push_back(ks);
+                }
+        return tab;
+    };
+    int rc = pack_stage<D>(s.w_o1, D, plain(C::KSD), wpk + (size_t)C::OFF_O1 * 512, stream, tmp);
+    if (!rc) rc = pack_stage<D>(s.w_q, D, plain(C::KSD), wpk + (size_t)C::OFF_Q * 512, stream, tmp);
+    if (!rc) rc = pack_stage<D>(s.w_o2, D, plain(C::KSD), wpk + (size_t)C::OFF_O2 * 512, stream, tmp);
+    if (!rc) rc = pack_stage<D>(s.w_m, 5 * D, plain(C::KSM), wpk + (size_t)C::OFF_M * 512, stream, tmp);
+    if (!rc) {
+        // GEGLU projection, source rows interleaved (2 j = value_j, 2 j + 1 = gate_j): chunk c, wave w, fragments
+        // (value, gate) of output block 2 w, then of 2 w + 1
+        std::vector<int> tab;
+        for (int c = 0; c < C::NCH; ++c)
+            for (int w = 0; w < TFM_NW; ++w)
+                for (int ks = 0; ks < C::KSD; ++ks)
+                    for (int f = 0; f < 4; ++f) {
+                        const int j0 = TFM_CH * c + 16 * (2 * w + (f >> 1));
+                        for (int i = 0; i < 16; ++i) tab.push_back(2 * (j0 + i) + (f & 1));
+                        tab.push_back(ks);
+                    }
+        rc = pack_stage<D>(s.w_g, D, tab, wpk + (size_t)C::OFF_G * 512, stream, tmp);
+    }
+    auto cp = [&](int off, const float* src, int n) { return hipMemcpyAsync(vec + off, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, stream); };
+    auto cp2 = [&](int off, const float* src, int n) { return hipMemcpy2DAsync(vec + off, 4, src, 8, 4, n, hipMemcpyDeviceToDevice, stream); };     // every second float
+    if (!rc) {
+        MKD_HIP_CHECK(cp(C::V_BO1, s.b_o1, D));
+        MKD_HIP_CHECK(cp(C::V_SQ, s.s_q, D));
+        MKD_HIP_CHECK(cp(C::V_BQ, s.b_q, D));
+        MKD_HIP_CHECK(cp(C::V_BO2, s.b_o2, D));
+        MKD_HIP_CHECK(cp2(C::V_SV, s.s_g, 4 * D));
+        MKD_HIP_CHECK(cp2(C::V_BV, s.b_g, 4 * D));
+        MKD_HIP_CHECK(cp2(C::V_SG, s.s_g + 1, 4 * D));
+        MKD_HIP_CHECK(cp2(C::V_BG, s.b_g + 1, 4 * D));
+        MKD_HIP_CHECK(cp(C::V_BM, s.b_m, D));
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    for (void* p : tmp) hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) return mkd_fail(-2, std::string("tfm_tail pack: ") + hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+bool tfm_tail_supported(int d, int heads, int T, int Tk) {
+    return d == 320 && heads == TFM_NW && T > 0 && T % TFM_TM == 0 && Tk > 0 && Tk <= 16 * TFM_KF;
+}
+size_t tfm_tail_weight_bytes(int d) { return d == 320 ? (size_t)TfmCfg<320>::UNITS * 1024 : 0; }
+size_t tfm_tail_vec_bytes(int d) { return d == 320 ? (size_t)TfmCfg<320>::V_TOTAL * sizeof(float) : 0; }
+size_t tfm_tail_kv_bytes(int d, int batch) { return d == 320 ? (size_t)batch * TFM_NW * TfmCfg<320>::KV_UNITS * 1024 : 0; }
+double tfm_tail_flops(int d, int M, int Tk) { return 2.0 * M * (16.0 * d * d + 2.0 * Tk * d); }
+
+int tfm_tail_pack_weights(int d, const TfmTailWeights& src, bf16_t* wpk, float* vec, hipStream_t stream) {
+    if (d != 320) return mkd_fail(-4, "tfm_tail: only d = 320 is built");
+    return pack_weights_t<320>(src, wpk, vec, stream);
+}
+
+int launch_tfm_tail_pack_kv(int d, const bf16_t* kv, int ldkv, int batch, int Tk, bf16_t* out, hipStream_t stream) {
+    if (d != 320) return mkd_fail(-4, "tfm_tail: only d = 320 is built");
+    if (Tk <= 0 || Tk > 16 * TFM_KF || ldkv % 8) return mkd_fail(-1, "tfm_tail kv pack: 1..80 keys, ld multiple of 8");
+    hipLaunchKernelGGL(tfm_pack_kv_kernel<320>, dim3(batch * TFM_NW), dim3(256), 0, stream, kv, ldkv, Tk, out);
+    MKD_LAUNCH_CHECK("tfm_pack_kv_kernel");
+    return 0;
+}
+
+int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1, int lda, const bf16_t* h0, int ldh, const bf16_t* xin, int ldx,
+                    const bf16_t* kvp, bf16_t* out, int ldo, int M, int T, int Tk, hipStream_t stream) {
+    if (!tfm_tail_supported(d, TFM_NW, T, Tk) || M <= 0 || M % TFM_TM) return mkd_fail(-4, "tfm_tail: unsupported shape");
+    if (lda % 8 || ldh % 4 || ldx % 4 || ldo % 4) return mkd_fail(-1, "tfm_tail: strides must be multiples of 8 (a1) / 4");
+    using C = TfmCfg<320>;
+    TfmTailArgs a;
+    a.wpk = (const bf16x8*)wpk; a.vec = vec; a.a1 = a1; a.lda = lda; a.h0 = h0; a.ldh = ldh; a.xin = xin; a.ldx = ldx;
+    a.kvp = (const bf16x8*)kvp; a.out = out; a.ldo = ldo; a.T = T; a.Tk = Tk;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)C::DH);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)tfm_tail_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(tfm_tail LDS): ") + hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(tfm_tail_kernel<320>, dim3(M / TFM_TM), dim3(64 * TFM_NW), C::LDS, stream, a);
+    MKD_LAUNCH_CHECK("tfm_tail_kernel");
+    return 0;
+}

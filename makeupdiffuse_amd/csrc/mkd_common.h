@@ -162,6 +162,26 @@ int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, flo
                      int rows, int d, hipStream_t stream, int ldx = 0, const NormIo* second = nullptr);      // ldx: input row stride (0 = d); y is dense
 int launch_merge_ff_out(const float* P, const float* W2, const float* b2, const float* bp, bf16_t* Wm, float* bias_m, int d,
                         hipStream_t stream);
+// ---- fused row-local transformer tail (kernels_tfm.hip) ----------------------------------------------------------------------
+// The tensors the engine's unfused path uses, all device pointers: attn1.to_out [d][d] + bias; attn2.to_q folded with LayerNorm 2
+// (W' = W diag(gamma), s = rowsum(W'), b' = W beta); attn2.to_out [d][d] + bias; the GEGLU projection folded with LayerNorm 3 with
+// (value, gate) rows interleaved [8d][d] (+ s, b' in the same order); the merged [ff.net.2 . proj_out | proj_out] weight [d][5d] + bias.
+struct TfmTailWeights {
+    const bf16_t* w_o1; const float* b_o1;
+    const bf16_t* w_q; const float* s_q; const float* b_q;
+    const bf16_t* w_o2; const float* b_o2;
+    const bf16_t* w_g; const float* s_g; const float* b_g;
+    const bf16_t* w_m; const float* b_m;
+};
+bool   tfm_tail_supported(int d, int heads, int T, int Tk);      // T tokens per sample, Tk context keys
+size_t tfm_tail_weight_bytes(int d);
+size_t tfm_tail_vec_bytes(int d);
+size_t tfm_tail_kv_bytes(int d, int batch);
+double tfm_tail_flops(int d, int M, int Tk);
+int tfm_tail_pack_weights(int d, const TfmTailWeights& src, bf16_t* wpk, float* vec, hipStream_t stream);       // synchronous
+int launch_tfm_tail_pack_kv(int d, const bf16_t* kv, int ldkv, int batch, int Tk, bf16_t* out, hipStream_t stream);
+int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1, int lda, const bf16_t* h0, int ldh, const bf16_t* xin, int ldx,
+                    const bf16_t* kvp, bf16_t* out, int ldo, int M, int T, int Tk, hipStream_t stream);
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
                      hipStream_t stream, int causal = 0, const AttnIo* second = nullptr);

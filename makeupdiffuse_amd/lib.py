@@ -91,6 +91,10 @@ SIGNATURES = {
     'mkd_gemm_ln_bf16': (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _F, _I, _P, _I, _I, _I, _I, _P]),
     'mkd_gemm_rowstats_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _P]),
     'mkd_groupnorm': (_I, [_P, _I, _P, _P, _F, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'mkd_tfm_tail_create': (_I, [_I] + [_P] * 15 + [C.POINTER(_P)]),
+    'mkd_tfm_tail_destroy': (None, [_P]),
+    'mkd_tfm_tail_set_context': (_I, [_P, _P, _I, _I, _I, _P]),
+    'mkd_tfm_tail_run': (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     'mkd_layernorm': (_I, [_P, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     'mkd_attention_causal': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
