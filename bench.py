@@ -47,13 +47,13 @@ def usable_cores() -> int:
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-MFMA_PREFIXES = ('gemm_', 'attention')
+MFMA_PREFIXES = ('gemm_', 'attention', 'tfm_tail')
 
 
 def _csrc_sha16():
     import hashlib
     src = b''.join(open(os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc', f), 'rb').read()
-                   for f in ('engine.hip', 'kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_misc.hip', 'gemm_tuned.inc'))
+                   for f in ('engine.hip', 'kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_tfm.hip', 'kernels_misc.hip', 'gemm_tuned.inc'))
     return hashlib.sha256(src).hexdigest()[:16]
 
 
@@ -367,7 +367,8 @@ def main():
         # 3x3 conv kernel, the attention kernel.  The dominant one (by device time) carries the roofline.
         fam = {'gemm_kernel': lambda k: k.startswith('gemm_') and 'patch' not in k,
                'conv3x3_patch_kernel': lambda k: k.startswith('gemm_') and 'patch' in k,
-               'attention_kernel': lambda k: k == 'attention'}
+               'attention_kernel': lambda k: k == 'attention',
+               'tfm_tail_kernel': lambda k: k == 'tfm_tail'}
         agg = {f: {'ms': sum(v['ms'] for k, v in prof.items() if sel(k)), 'flops': sum(v['flops'] for k, v in prof.items() if sel(k)),
                    'launches': sum(v['launches'] for k, v in prof.items() if sel(k))} for f, sel in fam.items()}
         dom = max(agg, key=lambda f: agg[f]['ms'])

@@ -275,6 +275,9 @@ int  mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16
 /* LayerNorm over the last dim of [rows, d] bf16. */
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
                   uint16_t* y, int rows, int d, void* stream);
+/* ... with a row stride on x (the engine normalises the h2 columns of its [gg | h2] buffer); y is dense. */
+int mkd_layernorm_ld(const uint16_t* x, int ldx, const float* gamma, const float* beta, float eps,
+                     uint16_t* y, int rows, int d, void* stream);
 /* softmax(q k^T * scale) v per (batch, head); q rows b*Tq+i, k/v rows b*Tk+j, head h at column h*dh. */
 int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv,
                   uint16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,

@@ -118,10 +118,10 @@ struct Op {
 
 // kinds: [K_GEMM_CONV, K_GEMM_LIN) conv GEMM by tile config, [K_GEMM_LIN, K_GROUPNORM) linear GEMM by tile config (both ranges
 // must hold gemm_num_tile_cfgs() entries: checked in mkd_ctx_create), then the rest
-enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 64, K_GROUPNORM = 128, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_MISC, K_COUNT };
+enum OpKind { K_GEMM_CONV = 0, K_GEMM_LIN = 64, K_GROUPNORM = 128, K_LAYERNORM, K_ATTENTION, K_GEGLU, K_CONV_DIRECT, K_TFM_TAIL, K_MISC, K_COUNT };
 
 std::string kind_name(int k) {
-    static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "misc"};
+    static const char* const rest[] = {"groupnorm", "layernorm", "attention", "geglu", "conv3x3_direct", "tfm_tail", "misc"};
     if (k < K_GEMM_LIN) return std::string("gemm_conv3x3_") + gemm_tile_cfg_name(k);
     if (k < K_GROUPNORM) return std::string("gemm_linear_") + gemm_tile_cfg_name(k - K_GEMM_LIN);
     return rest[k - K_GROUPNORM];
@@ -169,6 +169,12 @@ struct mkd_ctx {
     std::map<std::string, bf16_t*> qkv_plain, ffp_w; std::map<std::string, float*> ffp_b;     // the unfolded counterparts
     std::map<std::string, bf16_t*> ffm_w; std::map<std::string, float*> ffm_b;                // [P.W2 | P], P.b2 + bp: FF2 + proj_out as one GEMM
     bool merge_ffout = getenv("MKD_MERGE_FFOUT") ? atoi(getenv("MKD_MERGE_FFOUT")) != 0 : true;
+    // Fused row-local tail of the d = 320 transformer blocks (kernels_tfm.hip): everything after the self-attention product as ONE
+    // launch per block instead of 7.  tfm_w / tfm_v: the block's weights re-packed in the order a wave consumes them (built in
+    // finalize from the SAME folded tensors the unfused plan uses), tfm_kv: the cached context K / V in MFMA-operand order (built in
+    // the prepare plan).  tfm_tail: 0 off, 1 on where the kernel covers the shape, -1 (default) the shape policy of use_tfm_tail().
+    int tfm_tail = getenv("MKD_TFM_TAIL") ? atoi(getenv("MKD_TFM_TAIL")) : -1;
+    std::map<std::string, bf16_t*> tfm_w; std::map<std::string, float*> tfm_v; std::map<std::string, bf16_t*> tfm_kv;
     std::map<std::string, float*> f32_keep;      // fp32 copies of the weights that get folded (kept for re-finalize)
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
@@ -498,6 +504,7 @@ struct mkd_ctx {
         }
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
         q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear(); ffm_w.clear(); ffm_b.clear();
+        tfm_w.clear(); tfm_v.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
@@ -584,6 +591,17 @@ struct mkd_ctx {
                         if (rc) return rc;
                     }
                     ffg_w[p] = (bf16_t*)w2; ffg_b[p] = bv; ffg_s[p] = sv;
+                }
+                if (tfm_tail_weight_bytes(d) && cfg.num_heads == 8 && ffm_w.count(p)) {
+                    void* wp = nullptr; void* vp = nullptr;
+                    rc = dev_alloc(&wp, tfm_tail_weight_bytes(d)); if (rc) return rc;
+                    rc = dev_alloc(&vp, tfm_tail_vec_bytes(d)); if (rc) return rc;
+                    TfmTailWeights tw{wb(t + ".attn1.to_out.0.weight"), wf(t + ".attn1.to_out.0.bias"), q2_w.at(p), q2_s.at(p), q2_b.at(p),
+                                      wb(t + ".attn2.to_out.0.weight"), wf(t + ".attn2.to_out.0.bias"), ffg_w.at(p), ffg_s.at(p), ffg_b.at(p),
+                                      ffm_w.at(p), ffm_b.at(p)};
+                    rc = tfm_tail_pack_weights(d, tw, (bf16_t*)wp, (float*)vp, 0);
+                    if (rc) return rc;
+                    tfm_w[p] = (bf16_t*)wp; tfm_v[p] = (float*)vp;
                 }
             }
             std::vector<std::string> wn;
@@ -807,6 +825,14 @@ struct mkd_ctx {
         TA().release(mk);
     }
 
+    // Where the fused tail replaces the 7 launches (tools/bench_tfm_tail.py, profiles/exp_r4_tfm_tail_standalone.txt: 0.49 of the
+    // chain's time at M >= 16384 rows, 0.73 at 8192, 1.08 at 4096 - a workgroup streams the block's 3.3 MB of weights whatever M is).
+    bool use_tfm_tail(const std::string& p, int d, int M, int T, bool producer_ln, const GnOut& go) const {
+        if (tfm_tail == 0 || producer_ln || go.gst || !tfm_w.count(p) || !tfm_kv.count(p)) return false;
+        if (!tfm_tail_supported(d, cfg.num_heads, T, ctx_len()) || M % 64) return false;
+        return tfm_tail > 0 || M >= tfm_tail_min_rows;
+    }
+    int tfm_tail_min_rows = getenv("MKD_TFM_TAIL_MINROWS") ? atoi(getenv("MKD_TFM_TAIL_MINROWS")) : 4096;
     // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
     // b0: first sample of x inside the prepared batch (decoder lanes run on a batch slice; the cross-attention K/V cache is
     // indexed by absolute sample)
@@ -846,6 +872,15 @@ struct mkd_ctx {
           op_linear(a_in, d, M, d, f ? qkv_w.at(p) : qkv_plain.at(p), 3 * d, e, qkv, 3 * d); }
         bf16_t* a1 = buf(d);
         op_attn(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, a1, d, x.B, T, T, heads, dh);
+        if (use_tfm_tail(p, d, M, T, fl, go)) {          // everything below as one launch per 64-token tile
+            const bf16_t* wpk = tfm_w.at(p); const float* vec = tfm_v.at(p);
+            const bf16_t* kvp = tfm_kv.at(p) + (size_t)b0 * (tfm_tail_kv_bytes(d, 1) / sizeof(bf16_t));
+            const bf16_t* xin = x.p; const int ldx = x.ld, Tk = ctx_len();
+            push(*cur_plan, [=](hipStream_t st) { return launch_tfm_tail(d, wpk, vec, a1, d, h0, d, xin, ldx, kvp, out, ldo, M, T, Tk, st); },
+                 1, tfm_tail_flops(d, M, Tk), K_TFM_TAIL, "M=" + std::to_string(M) + " d=" + std::to_string(d) + " T=" + std::to_string(T));
+            TA().release(mk);
+            return;
+        }
         bf16_t* h1 = buf(d);
         { Epi e; e.bias = wf(t + ".attn1.to_out.0.bias"); e.R = h0; e.ldr = d; e.stat_out = st1;
           op_linear(a1, d, M, d, wb(t + ".attn1.to_out.0.weight"), d, e, h1, d); }
@@ -1073,7 +1108,7 @@ struct mkd_ctx {
             bf16_t* dst = ctx_bf16; const int64_t n = (int64_t)B * L * cd;
             push(*cur_plan, [self, dst, n](hipStream_t st) { return launch_f32_to_bf16(self->in_context, dst, n, st); }, 1, 0.0);
         }
-        kv_cache.clear();
+        kv_cache.clear(); tfm_kv.clear();
         for (int which = 0; which < 2; ++which) {
             if (which == 1 && !has_control) continue;
             for (auto& p : st_prefixes[which]) {
@@ -1083,6 +1118,12 @@ struct mkd_ctx {
                 Epi e;
                 op_linear(ctx_bf16, cd, B * L, cd, kv_w.at(p), 2 * d, e, kv.p, 2 * d);
                 kv_cache[p] = kv;
+                if (tfm_w.count(p) && tfm_tail != 0 && L <= 80) {
+                    bf16_t* kp = (bf16_t*)persist.alloc(tfm_tail_kv_bytes(d, B));
+                    const bf16_t* src = kv.p; const int Bn = B;
+                    push(*cur_plan, [src, d, Bn, L, kp](hipStream_t st) { return launch_tfm_tail_pack_kv(d, src, 2 * d, Bn, L, kp, st); }, 1, 0.0, K_MISC, "tfm_kv_pack");
+                    tfm_kv[p] = kp;
+                }
             }
         }
         if (has_control) {
@@ -2291,6 +2332,15 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
     if (cfg->context_dim % 8) return mkd_fail(MKD_ERR_UNSUPPORTED, "context_dim must be a multiple of 8");
     for (int j = 0; j < 7; ++j)
         if (cfg->hint_widths[j] % 8) return mkd_fail(MKD_ERR_UNSUPPORTED, "hint widths must be multiples of 8");
+    // A sampling step is replayed as ONE captured graph whose two branches (ControlNet / UNet encoder, then the decoder lanes) run on
+    // different hardware queues and meet at join nodes: barrier packets that wait on the completion signals of kernels of ANOTHER
+    // queue.  ROC_SYSTEM_SCOPE_SIGNAL=0 makes the runtime create those signals without system scope; a cross-queue barrier-AND on
+    // such a signal was observed never to be satisfied (round 3, profiles/exp_r3_rt_env2.txt: the first graph replay did not
+    // complete in 420 s).  Refuse the setting instead of hanging the device.
+    if (const char* ss = getenv("ROC_SYSTEM_SCOPE_SIGNAL"))
+        if (ss[0] && atoi(ss) == 0)
+            return mkd_fail(MKD_ERR_UNSUPPORTED, "ROC_SYSTEM_SCOPE_SIGNAL=0 is not supported: the step graph's cross-queue join barriers wait on "
+                                                 "completion signals that need system scope (a graph replay never completes); unset it");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mkd_fail(MKD_ERR_HIP, "no HIP device visible: libmkd has no CPU path");
@@ -2566,6 +2616,9 @@ int mkd_groupnorm(const uint16_t* x, int ld_in, const float* gamma, const float*
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps, uint16_t* y, int rows, int d, void* stream) {
     return launch_layernorm(x, gamma, beta, eps, y, rows, d, (hipStream_t)stream);
 }
+int mkd_layernorm_ld(const uint16_t* x, int ldx, const float* gamma, const float* beta, float eps, uint16_t* y, int rows, int d, void* stream) {
+    return launch_layernorm(x, gamma, beta, eps, y, rows, d, (hipStream_t)stream, ldx);
+}
 int mkd_attention(const uint16_t* q, int ldq, const uint16_t* k, int ldk, const uint16_t* v, int ldv, uint16_t* o, int ldo,
                   int batch, int Tq, int Tk, int heads, int dh, float scale, void* stream) {
     return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, batch, Tq, Tk, heads, dh, scale, (hipStream_t)stream);
@@ -2625,6 +2678,8 @@ int mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, c
     *out = h;
     return 0;
 }
+/* experiment builds (-DMKD_TFM_TRACE) only: device buffer [workgroups][8][32] of int64 time stamps; a no-op in the product build */
+int mkd_debug_tfm_trace(long long* buf) { tfm_tail_set_trace(buf); return 0; }
 int mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream) {
     if (!h) return mkd_fail(MKD_ERR_ARG, "null handle");
     if (batch > h->kv_batch) {

@@ -61,7 +61,8 @@ struct TfmCfg {
                          V_BM = 20 * D, V_TOTAL = 21 * D;
     static constexpr int BUF = TFM_TM * D * 2;            // one activation tile in LDS
     static constexpr int GBUF = TFM_MF * TFM_GKS * 1024;
-    static constexpr int LDS = 2 * BUF + GBUF + 2 * TFM_NW * TFM_TM * 8;
+    static constexpr int PF_OFF = 2 * BUF + GBUF + 2 * TFM_NW * TFM_TM * 8;      // 256 B per wave: landing pad of the L2 warm-up loads
+    static constexpr int LDS = PF_OFF + TFM_NW * 256;
     static_assert(D % 64 == 0 && DH % 8 == 0 && (4 * D) % TFM_CH == 0 && GBUF <= BUF, "tile geometry");
 };
 
@@ -76,7 +77,14 @@ struct TfmTailArgs {
     int T;                      // tokens per sample (multiple of TFM_TM)
     int Tk;                     // context keys (<= 16 * TFM_KF)
     float scale_log2e;          // dh^-0.5 * log2(e)
+    long long* trace;           // MKD_TFM_TRACE builds only: [workgroup][wave][32] wall_clock64 stamps (tools/exp_r4_tfm_trace.py)
 };
+
+#ifdef MKD_TFM_TRACE
+#define TFM_STAMP(i) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * TFM_NW + w) * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define TFM_STAMP(i) do { } while (0)
+#endif
 
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
@@ -102,12 +110,19 @@ __device__ __forceinline__ void stage_mm(const bf16x8* __restrict__ wp, const ch
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int mf = 0; mf < TFM_MF; ++mf)
+            for (int mf = 0; mf < TFM_MF; ++mf) {
+#ifdef TFM_EXP_NOMFMA           // (experiment build: operands stay live, no matrix instruction - wrong numbers)
+                asm volatile("" :: "v"(wr[ks % TFM_PD][f]), "v"(xf[mf]));
+#else
                 acc[f][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ks % TFM_PD][f], xf[mf], acc[f][mf], 0, 0, 0);
+#endif
+            }
+#ifndef TFM_EXP_NOLOAD          // (experiment build: the k-loop re-uses its first TFM_PD weight steps - wrong numbers, no weight stream)
         if (ks + TFM_PD < KS) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) wr[ks % TFM_PD][f] = wp[((ks + TFM_PD) * NF + f) * 64];
         }
+#endif
     }
 }
 
@@ -172,6 +187,7 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
         stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O1 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        TFM_STAMP(2);
         float s[TFM_MF], q[TFM_MF];
 #pragma unroll
         for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
@@ -191,9 +207,11 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
                 *(U16x4*)(bufB + out_off(mf, fr0 + f)) = o;
             }
         }
+        TFM_STAMP(3);
         put_stats(s, q, st1, w, r, g);
     }
     __syncthreads();
+    TFM_STAMP(4);
 
     // ---- S2: q = attn2.to_q(LN2(h1)) -> bufA (a1 is dead) --------------------------------------------------------------
     {
@@ -202,6 +220,7 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
         stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_Q + C::KSD * fr0) * 64, bufB + lane * 16, xs, acc);
+        TFM_STAMP(5);
 #pragma unroll
         for (int f = 0; f < NFN; ++f) {
             const float4 ss = *(const float4*)(vec + C::V_SQ + 16 * (fr0 + f) + 4 * g);
@@ -216,7 +235,9 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
             }
         }
     }
+    TFM_STAMP(6);
     __syncthreads();
+    TFM_STAMP(7);
 
     // ---- S3: cross-attention over the cached context, wave = head; a2 overwrites q in place --------------------------
     {
@@ -304,13 +325,16 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
             }
         }
     }
+    TFM_STAMP(8);
     __syncthreads();
+    TFM_STAMP(9);
 
     // ---- S4: h2 = attn2.to_out(a2) + h1 -> bufB in place, row statistics -> st2 ----------------------------------------
     {
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
         stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O2 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        TFM_STAMP(10);
         float s[TFM_MF], q[TFM_MF];
 #pragma unroll
         for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
@@ -332,9 +356,11 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
                 *(U16x4*)p = o;
             }
         }
+        TFM_STAMP(11);
         put_stats(s, q, st2, w, r, g);
     }
     __syncthreads();
+    TFM_STAMP(12);
 
     // ---- S5 / S6: GEGLU chunks -> double-buffered LDS tile -> merged [ff.net.2 . proj_out | proj_out] accumulator -----------
     f32x4 accF[NFN][TFM_MF];
@@ -350,6 +376,7 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
                 f32x4 acc[4][TFM_MF];
                 zero_acc<4>(acc);
                 stage_mm<4, C::KSD>(wp + (size_t)(C::OFF_G + (c * TFM_NW + w) * 4 * C::KSD) * 64, bufB + lane * 16, xs, acc);
+                if (c == 1) TFM_STAMP(13);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int col = 16 * (2 * w + p) + 4 * g;           // column inside the chunk
@@ -371,11 +398,16 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
                     }
                 }
             }
+            if (c == 1) TFM_STAMP(14);
             __syncthreads();
+            if (c == 1) TFM_STAMP(15);
             stage_mm<NFN, TFM_GKS>(wm + (size_t)(c * TFM_GKS * NFN) * 64, G + lane * 16, TFM_GKS * 1024, accF);
+            if (c == 1) TFM_STAMP(16);
+            if (c == C::NCH - 1) TFM_STAMP(17);
         }
         // the h2 part of the merged GEMM (K columns 4d .. 5d)
         stage_mm<NFN, C::KSD>(wm + (size_t)(C::NCH * TFM_GKS * NFN) * 64, bufB + lane * 16, xs, accF);
+        TFM_STAMP(18);
     }
 
     // ---- out = accF + (proj_out . b2 + b_proj_out) + x_in ----------------------------------------------------------------
@@ -394,6 +426,7 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
             *(U16x4*)(a.out + row * a.ldo + n) = o;
         }
     }
+    TFM_STAMP(19);
 }
 
 template <int D>
@@ -401,6 +434,20 @@ __global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs
     using C = TfmCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // L2 warm-up.  Every workgroup streams ALL the block's weights (3.3 MB, they fit the XCD's 4 MiB L2), and the workgroups of an
+    // XCD run in step: left to demand loads, every line is an HBM miss for all of them at once and the kernel runs at
+    // (bytes in flight per workgroup) / (HBM latency).  So the workgroups of an XCD split the stream: workgroup i of the XCD
+    // (workgroups are dealt round-robin, blockIdx / 8 numbers them - a speed assumption only) touches granule i, i + n, ... once at
+    // kernel start (one dword per 64 B, landing in an LDS pad nobody reads); the demand loads then find L2 hits.
+    {
+        const int nsl = min(16, max(1, (int)gridDim.x >> 3)), sl = ((int)blockIdx.x >> 3) % nsl;
+        const char* base = (const char*)a.wpk + lane * 64;
+        char* pad = smem + C::PF_OFF + w * 256;
+        for (int gi = sl + nsl * w; gi < C::UNITS / 4; gi += nsl * TFM_NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)gi * 4096),
+                                             (__attribute__((address_space(3))) void*)pad, 4, 0, 0);
+    }
+    TFM_STAMP(0);
     // a1 tile -> bufA in operand order: 1 KiB block (mf, ks) = 64 lanes x 16 B, lane (g, r) holds a1[16 mf + r][32 ks + 8 g ..]
     {
         const int row0 = blockIdx.x * TFM_TM;
@@ -416,6 +463,7 @@ __global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs
         for (int i = 0; i < PER; ++i) *(U16x8*)(smem + ((w + i * TFM_NW) * 64 + lane) * 16) = t[i];
     }
     __syncthreads();
+    TFM_STAMP(1);
     if (C::NWA == TFM_NW || w < C::NWA) tfm_wave<D, C::NFA>(a, smem, w, lane, w * C::NFA);
     else tfm_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
 }
@@ -527,6 +575,9 @@ int pack_weights_t(const TfmTailWeights& s, bf16_t* wpk, float* vec, hipStream_t
 
 }  // namespace
 
+static long long* g_tfm_trace = nullptr;
+void tfm_tail_set_trace(long long* buf) { g_tfm_trace = buf; }       // MKD_TFM_TRACE builds: device buffer [workgroups][8][32]
+
 bool tfm_tail_supported(int d, int heads, int T, int Tk) {
     return d == 320 && heads == TFM_NW && T > 0 && T % TFM_TM == 0 && Tk > 0 && Tk <= 16 * TFM_KF;
 }
@@ -557,6 +608,7 @@ int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1
     a.wpk = (const bf16x8*)wpk; a.vec = vec; a.a1 = a1; a.lda = lda; a.h0 = h0; a.ldh = ldh; a.xin = xin; a.ldx = ldx;
     a.kvp = (const bf16x8*)kvp; a.out = out; a.ldo = ldo; a.T = T; a.Tk = Tk;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)C::DH);
+    a.trace = g_tfm_trace;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)tfm_tail_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);

@@ -173,6 +173,7 @@ struct TfmTailWeights {
     const bf16_t* w_g; const float* s_g; const float* b_g;
     const bf16_t* w_m; const float* b_m;
 };
+void   tfm_tail_set_trace(long long* buf);
 bool   tfm_tail_supported(int d, int heads, int T, int Tk);      // T tokens per sample, Tk context keys
 size_t tfm_tail_weight_bytes(int d);
 size_t tfm_tail_vec_bytes(int d);

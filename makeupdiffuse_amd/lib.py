@@ -96,6 +96,7 @@ SIGNATURES = {
     'mkd_tfm_tail_set_context': (_I, [_P, _P, _I, _I, _I, _P]),
     'mkd_tfm_tail_run': (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     'mkd_layernorm': (_I, [_P, _P, _P, _F, _P, _I, _I, _P]),
+    'mkd_layernorm_ld': (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     'mkd_attention_causal': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     'mkd_geglu': (_I, [_P, _P, _I, _I, _P]),

@@ -219,6 +219,19 @@ def test_full_size_eps_vs_oracle():
     eng.prepare(hint, ctx)
     r, c = check_eps(eng.eps(x, t), ref, what='full-size eps')
     print(f'full-size eps: rel-L2 {r:.4e} cos {c:.6f} launches {eng.eps_launches()} GFLOP {eng.eps_flops() / 1e9:.1f}')
+    # the same evaluation with the fused transformer tail forced on (batch 1 is below its shape policy's threshold)
+    os.environ['MKD_TFM_TAIL'] = '1'
+    try:
+        eng_f = MkdEngine(NetConfig())
+    finally:
+        os.environ.pop('MKD_TFM_TAIL')
+    eng_f.load_state_dict(sd_ref)
+    eng_f.prepare(hint, ctx)
+    rf, cf = check_eps(eng_f.eps(x, t), ref, what='full-size eps, fused transformer tail')
+    print(f'full-size eps, fused transformer tail: rel-L2 {rf:.4e} cos {cf:.6f} launches {eng_f.eps_launches()}')
+    # (7 d = 320 blocks; at batch 1 the unfused tail is 6 launches - LayerNorm 3 is taken on the fly there - against 1)
+    assert eng.eps_launches() - eng_f.eps_launches() == 35 and abs(eng_f.eps_flops() - eng.eps_flops()) < 1e6
+    eng_f.close()
     # 121.42 GMAC per sample per eval, minus what mkd_prepare caches once per batch:
     # hint block 1.87 GMAC + cross-attention K/V projections 2.16 GMAC -> 117.39 GMAC executed per eval
     assert abs(eng.eps_flops() / 2e9 - 117.39) < 0.05

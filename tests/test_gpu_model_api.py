@@ -123,6 +123,45 @@ def test_mkddim_sampler_on_device_vs_golden(model, G):
         s.denoising_step(x, c, ts, index=6, dynamic_threshold=0.5)              # cddim.py:70-71
 
 
+def test_ddim_sampler_eta_positive_on_device_vs_oracle(model, G, weights, monkeypatch):
+    """the stochastic branch of the step (reference diffmk/cddim.py:74-78: x_prev += sigma_t * randn * temperature)
+    through the CLASS on the device - DDIMSampler.sample(eta = 0.5), which leaves the in-library loop for the per-step path - with the
+    noise draws injected, against oracle.sampler.denoising_step(noise=...) driven by the same draws; with and without guidance."""
+    import makeupdiffuse_amd.ddim as ddim_mod
+    from makeupdiffuse_amd.ddim import DDIMSampler
+    ocfg, sd, _, _ = weights
+    S, eta, temp = 5, 0.5, 0.8
+    x = G['x']
+    g = torch.Generator().manual_seed(77)
+    draws = [torch.randn(x.shape, generator=g) for _ in range(S)]
+    c = cond_of(G)
+    c_cpu = {'c_crossattn': [G['ctx']], 'c_concat': [G['hint']]}
+    uc = {'c_crossattn': [G['uctx'].cuda()], 'c_concat': c['c_concat']}
+    uc_cpu = {'c_crossattn': [G['uctx']], 'c_concat': [G['hint']]}
+    eps_fn = sampler.make_eps_fn(sd, ocfg)
+    for scale, ucond, ucond_cpu, lim in ((1.0, None, None, (1.5e-2, 0.9995)), (9.0, uc, uc_cpu, (6e-2, 0.998))):
+        sch = sampler.Schedule(); sch.make_ddim(S, eta)
+        assert float(sch.ddim_sigmas.abs().max()) > 0
+        ref = x.clone()
+        for i, step in enumerate(np.flip(sch.ddim_timesteps)):
+            index = S - i - 1
+            ts = torch.full((x.shape[0],), int(step), dtype=torch.long)
+            ref, _ = sampler.denoising_step(eps_fn, sch, ref, c_cpu, ts, index, scale, ucond_cpu, temperature=temp, noise=draws[i])
+        used = []
+        def fake_noise(shape, device, repeat=False):
+            used.append(len(used))
+            return draws[len(used) - 1].to(device)
+        monkeypatch.setattr(ddim_mod, 'noise_like', fake_noise)
+        smp = DDIMSampler(model)
+        out, _ = smp.sample(S, x.shape[0], tuple(x.shape[1:]), conditioning=c, eta=eta, temperature=temp, x_T=x.cuda(), verbose=False,
+                            unconditional_guidance_scale=scale, unconditional_conditioning=ucond)
+        assert used == list(range(S))                      # one draw per step: the stochastic branch ran every step
+        check(out, ref, lim[0], lim[1], f'DDIMSampler.sample(eta=0.5, temperature=0.8, scale={scale})')
+        det, _ = smp.sample(S, x.shape[0], tuple(x.shape[1:]), conditioning=c, eta=0.0, x_T=x.cuda(), verbose=False,
+                            unconditional_guidance_scale=scale, unconditional_conditioning=ucond)
+        assert metrics(det, ref)[0] > 5e-2                 # the noise does move the latent: not a vacuous comparison
+
+
 def test_log_results_two_passes_vs_golden(model, G):
     """What runs/test.py runs per batch (diffusion_makeup.py:391-410): 50 DDIM steps plain, then CFG 9 with the SAME hint in the
     unconditional branch; latents and decoded images against the oracle's sample() x 2 and decode_first_stage."""

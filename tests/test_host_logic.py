@@ -3,6 +3,7 @@ arithmetic) and the C ABI's symbol table.  No compute is run through libmkd here
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -46,6 +47,22 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
     h = ctypes.c_void_p()
     assert lib.mkd_ctx_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
     assert b'no CPU path' in lib.mkd_last_error() or b'HIP' in lib.mkd_last_error()
+
+
+def test_system_scope_signal_switch_is_refused_loudly():
+    """with ROC_SYSTEM_SCOPE_SIGNAL=0 a replay of the step graph never completed (profiles/exp_r3_rt_env2.txt: the
+    cross-queue join barriers wait on completion signals that need system scope).  mkd_ctx_create refuses the setting - before it
+    looks for a device, so this runs on the CPU; nothing is launched."""
+    import subprocess
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from makeupdiffuse_amd import lib as m; from makeupdiffuse_amd.engine import NetConfig; "
+            "l = m.load(); c = NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64, "
+            "hint_widths=(16, 16, 32, 32, 32, 32, 64)).to_c(); h = ctypes.c_void_p(); rc = l.mkd_ctx_create(ctypes.byref(c), ctypes.byref(h)); "
+            "print(rc, l.mkd_last_error().decode())" % ROOT)
+    for val, refused in (('0', True), ('1', False)):
+        env = dict(os.environ, ROC_SYSTEM_SCOPE_SIGNAL=val)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120).stdout
+        rc = int(out.split()[0])
+        assert (rc == -4 and 'ROC_SYSTEM_SCOPE_SIGNAL' in out) == refused, out
 
 
 def test_product_does_not_import_the_oracle():
@@ -302,7 +319,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     csrc = os.path.join(ROOT, 'makeupdiffuse_amd', 'csrc')
-    for src in ('kernels_gemm.hip', 'kernels_conv.hip', 'kernels_attn.hip', 'kernels_norm.hip'):
+    for src in ('kernels_gemm.hip', 'kernels_conv.hip', 'kernels_attn.hip', 'kernels_norm.hip', 'kernels_tfm.hip'):
         out = tmp_path / (src + '.s')
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-I', csrc, '-S',
                                '--cuda-device-only', os.path.join(csrc, src), '-o', str(out)], stderr=subprocess.DEVNULL)

@@ -9,7 +9,7 @@ obj=$src/_obj/variant_$name
 mkdir -p $obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -ffp-contract=fast"
 pids=()
-for f in kernels_gemm kernels_conv kernels_norm kernels_attn kernels_misc engine; do
+for f in kernels_gemm kernels_conv kernels_norm kernels_attn kernels_tfm kernels_misc engine; do
   hipcc $FLAGS "$@" -c $src/$f.hip -o $obj/$f.o &
   pids+=($!)
 done

@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_summary; mkdir -p $OUT
 # provenance: gpurun snapshots carry no .git, so the caller passes the commit (MKD_HEAD=$(git rev-parse --short HEAD) gpurun ...)
 python3 - <<PY > $OUT/r3_provenance.json
 import json, time, hashlib
-src = b''.join(open('makeupdiffuse_amd/csrc/' + f, 'rb').read() for f in ('engine.hip', 'kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_misc.hip', 'gemm_tuned.inc'))
+src = b''.join(open('makeupdiffuse_amd/csrc/' + f, 'rb').read() for f in ('engine.hip', 'kernels_gemm.hip', 'kernels_conv.hip', 'kernels_norm.hip', 'kernels_attn.hip', 'kernels_tfm.hip', 'kernels_misc.hip', 'gemm_tuned.inc'))
 print(json.dumps({'commit': '${MKD_HEAD:-unknown}', 'utc': time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime()), 'csrc_sha256_16': hashlib.sha256(src).hexdigest()[:16],
                   'commands': 'tools/collect_profiles.sh (rocprofv3 --kernel-trace --stats of bench.py; one --pmc pass per counter set, kernel-trace only)'}))
 PY
