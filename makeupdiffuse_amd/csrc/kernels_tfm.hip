@@ -11,10 +11,14 @@
 //   * every product is computed TRANSPOSED, out^T[n][m] = sum_k W[n][k] X[m][k] with v_mfma_f32_16x16x32_bf16: W fragments are the
 //     A operand, the 64-token activation tile the B operand.  The waves split the OUTPUT CHANNELS only, so a weight fragment is
 //     needed by exactly one wave: it goes from L2 straight into that wave's registers, 1 KiB contiguous per wave-instruction
-//     (weights are re-packed once at load time in exactly the order a wave consumes them), TFM_PD k-steps ahead; only activations
-//     live in LDS;
+//     (weights are re-packed once at load time in exactly the order a wave consumes them) by raw buffer loads (descriptor and
+//     stream offset in SGPRs: no per-lane 64-bit address arithmetic), TFM_PD k-steps ahead - ACROSS stages: the last k-steps of a
+//     stage load the first k-steps of the next one, so the stream stays in flight over the epilogue and the barrier between them;
+//     only activations live in LDS;
 //   * activations sit in LDS in MFMA-operand order, tile[16-row fragment][32-wide k-step][lane][8]: a B fragment is ONE lane-linear
-//     ds_read_b128 (conflict-free), and an epilogue lane (4 consecutive channels of one token) stores ONE 8-byte word;
+//     ds_read_b128 (conflict-free), and an epilogue lane (4 consecutive channels of one token) stores ONE 8-byte word; the a1 tile
+//     arrives in that order by LDS-DMA (global_load_lds_dwordx4 with a per-lane source address), and so do the block's bias /
+//     LayerNorm-correction vectors (27 KB), which every epilogue then reads from LDS;
 //   * LayerNorm 2 / 3 are folded into the consumer's weights (W' = W diag(gamma), s = rowsum(W'), b' = b + W beta: the same folded
 //     tensors the engine's LayerNorm-on-the-fly GEMM uses) and the epilogue applies rstd (acc - mean s) + b'; the row statistics are
 //     taken from the bf16-rounded values the producing epilogue holds (per-wave partials in LDS, summed in fixed order:
@@ -23,9 +27,11 @@
 //     by the [ff.net.2 . proj_out | proj_out] accumulator (the merged K = 5d weight of DESIGN.md §4.2): it never exists in memory;
 //   * cross-attention: wave = head.  K and V of the (sample, head) come pre-packed in MFMA-operand order (built once per
 //     mkd_prepare beside the K/V cache: the context is constant over the steps), scores are computed transposed so a lane owns
-//     one query, P feeds P.V from the accumulator registers (k order permuted identically in the packed V).
+//     one query, P feeds P.V from the accumulator registers (k order permuted identically in the packed V);
+//   * the workgroups of an XCD split an L2 warm-up of the weight stream among themselves at kernel start (tfm_prologue).
 // Per workgroup: 3.3 MB of weights (d = 320) streamed once from L2, 13.4 K MFMAs; HBM sees the a1 / h0 / x_in tiles in and the
-// block output out.
+// block output out.  Measured (profiles/exp_r4_tfm_*): 67 us per workgroup generation alone on the chip against
+// 94 us for the 7 launches at 8192 rows, 146 against 302 us at 32768; in the loop +4 % (batch 8) to +7 % (interpolation batch).
 #include "mkd_common.h"
 #include <vector>
 
@@ -36,7 +42,10 @@ constexpr int TFM_TM = 64;           // tokens per workgroup
 constexpr int TFM_MF = TFM_TM / 16;  // 16-token B fragments
 constexpr int TFM_CH = 256;          // GEGLU output columns per chunk
 constexpr int TFM_GKS = TFM_CH / 32; // k-steps of one chunk in the merged FF GEMM
-constexpr int TFM_PD = 3;            // weight k-steps in flight per wave
+#ifndef MKD_TFM_PD
+#define MKD_TFM_PD 2
+#endif
+constexpr int TFM_PD = MKD_TFM_PD;   // weight k-steps in flight per wave
 constexpr int TFM_KF = 5;            // 16-key fragments of the context (<= 80 keys)
 constexpr int TFM_PVS = 3;           // 32-key steps of P.V (96 >= 80)
 
@@ -62,7 +71,8 @@ struct TfmCfg {
     static constexpr int BUF = TFM_TM * D * 2;            // one activation tile in LDS
     static constexpr int GBUF = TFM_MF * TFM_GKS * 1024;
     static constexpr int PF_OFF = 2 * BUF + GBUF + 2 * TFM_NW * TFM_TM * 8;      // 256 B per wave: landing pad of the L2 warm-up loads
-    static constexpr int LDS = PF_OFF + TFM_NW * 256;
+    static constexpr int VEC_OFF = PF_OFF + TFM_NW * 256;                         // the packed vectors, V_TOTAL floats
+    static constexpr int LDS = VEC_OFF + V_TOTAL * 4;
     static_assert(D % 64 == 0 && DH % 8 == 0 && (4 * D) % TFM_CH == 0 && GBUF <= BUF, "tile geometry");
 };
 
@@ -91,17 +101,40 @@ typedef short s16x8v __attribute__((ext_vector_type(8)));
 // byte offset of the 16-byte chunk (token row, 8-channel group c) inside a tile with KS k-steps per row fragment
 __device__ __forceinline__ int lds_chunk(int mf, int c, int r, int KS) { return (((mf * KS + (c >> 2)) << 6) + ((c & 3) << 4) + r) << 4; }
 
-// acc[f][mf] += W fragment (f, ks) x activation fragment (mf, ks) over KS k-steps.  wp: the wave's packed stream, unit order
-// [ks][f], already offset by the lane; xb: LDS tile + lane * 16 (+ first k-step * 1024); xs: bytes between row fragments.
-template <int NF, int KS>
-__device__ __forceinline__ void stage_mm(const bf16x8* __restrict__ wp, const char* xb, int xs, f32x4 (&acc)[NF][TFM_MF]) {
-    bf16x8 wr[TFM_PD][NF];
+__device__ __forceinline__ void warm64(const void* p, char* pad) {      // pull one 64-byte segment per lane towards L2 (lands in a pad nobody reads)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)pad, 4, 0, 0);
+}
+
+// The weight stream of a wave: TFM_PD k-steps of NF fragments in registers.  A stage consumes slot ks % TFM_PD at k-step ks and
+// refills it with k-step ks + TFM_PD - or, in its last TFM_PD k-steps, with the first k-steps of the NEXT stage's stream, so that
+// the loads stay in flight across the epilogue and the workgroup barrier between two stages.
+template <int NF> struct Ring { bf16x8 r[TFM_PD][NF]; };
+// one 1 KiB unit of a wave's stream by a raw buffer load: resource descriptor and stream offset in SGPRs (scalar adds), the lane's
+// 16 bytes as the only VGPR operand - no 64-bit per-lane address arithmetic in the k-loops
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+struct WStream { __amdgpu_buffer_rsrc_t rs; int off; };          // off: byte offset of the stream inside the buffer (wave-uniform)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 ldw(const WStream& w, unsigned lo, int unit) {
+    const i32x4v v = __builtin_amdgcn_raw_buffer_load_b128(w.rs, (int)lo, w.off + unit * 1024, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int NF>
+__device__ __forceinline__ void ring_fill(Ring<NF>& R, const WStream& wp, unsigned lo) {
 #pragma unroll
     for (int p = 0; p < TFM_PD; ++p)
-        if (p < KS) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) wr[p][f] = wp[(p * NF + f) * 64];
-        }
+        for (int f = 0; f < NF; ++f) R.r[p][f] = ldw(wp, lo, p * NF + f);
+}
+
+// acc[f][mf] += W fragment (f, ks) x activation fragment (mf, ks) over KS k-steps.  wp: the wave's packed stream (wave-uniform
+// pointer), unit order [ks][f]; lo: the lane's byte offset inside a unit; cur holds its first TFM_PD k-steps; nxt / wpn: ring and stream of the stage that follows
+// (NEXT = false: none).  xb: LDS tile + lane * 16 (+ first k-step * 1024); xs: bytes between row fragments.
+template <int NF, int KS, bool NEXT, int NFX>
+__device__ __forceinline__ void stage_mm(Ring<NF>& cur, const WStream& wp, Ring<NFX>& nxt, const WStream& wpn, unsigned lo,
+                                         const char* xb, int xs, f32x4 (&acc)[NF][TFM_MF]) {
+    static_assert(KS >= TFM_PD, "a stage is at least TFM_PD k-steps long");
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         bf16x8 xf[TFM_MF];
@@ -112,15 +145,25 @@ __device__ __forceinline__ void stage_mm(const bf16x8* __restrict__ wp, const ch
 #pragma unroll
             for (int mf = 0; mf < TFM_MF; ++mf) {
 #ifdef TFM_EXP_NOMFMA           // (experiment build: operands stay live, no matrix instruction - wrong numbers)
-                asm volatile("" :: "v"(wr[ks % TFM_PD][f]), "v"(xf[mf]));
+                asm volatile("" :: "v"(cur.r[ks % TFM_PD][f]), "v"(xf[mf]));
 #else
-                acc[f][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ks % TFM_PD][f], xf[mf], acc[f][mf], 0, 0, 0);
+                acc[f][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.r[ks % TFM_PD][f], xf[mf], acc[f][mf], 0, 0, 0);
 #endif
             }
-#ifndef TFM_EXP_NOLOAD          // (experiment build: the k-loop re-uses its first TFM_PD weight steps - wrong numbers, no weight stream)
+#ifndef TFM_EXP_NOLOAD          // (experiment build: every k-loop re-uses the first TFM_PD weight steps - wrong numbers, no weight stream)
         if (ks + TFM_PD < KS) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) wr[ks % TFM_PD][f] = wp[((ks + TFM_PD) * NF + f) * 64];
+            for (int f = 0; f < NF; ++f) cur.r[ks % TFM_PD][f] = ldw(wp, lo, (ks + TFM_PD) * NF + f);
+        } else if (NEXT) {
+            const int p = ks + TFM_PD - KS;
+#pragma unroll
+            for (int f = 0; f < NFX; ++f) nxt.r[p][f] = ldw(wpn, lo, p * NFX + f);
+        }
+#else
+        if (NEXT && ks + TFM_PD >= KS) {
+            const int p = ks + TFM_PD - KS;
+#pragma unroll
+            for (int f = 0; f < NFX; ++f) nxt.r[p][f] = cur.r[p][f < NF ? f : 0];
         }
 #endif
     }
@@ -157,8 +200,52 @@ __device__ __forceinline__ void get_stats(const float2* st, int r, float (&mean)
         rstd[mf] = __builtin_amdgcn_rsqf(var + 1e-5f);
     }
 }
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 
-// the program of one wave; NFN = its share of the 16-channel fragments of an N = D product, fr0 = the first of them
+// Start of a workgroup: the a1 tile and the vectors into LDS by LDS-DMA, the L2 warm-up; completes on the caller's vmcnt(0) + barrier
+template <int D>
+__device__ __forceinline__ void tfm_prologue(const TfmTailArgs& a, char* smem, const int w, const int lane) {
+    using C = TfmCfg<D>;
+    const int row0 = blockIdx.x * TFM_TM;
+    // a1 tile -> bufA in operand order: 1 KiB block (mf, ks) = 64 lanes x 16 B, lane (g, r) supplies the address of
+    // a1[16 mf + r][32 ks + 8 g ..]
+    constexpr int PER = TFM_MF * C::KSD / TFM_NW;
+    static_assert(TFM_MF * C::KSD % TFM_NW == 0, "a1 tile blocks per wave");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int blk = w + i * TFM_NW, mf = blk / C::KSD, ks = blk - mf * C::KSD;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.a1 + (size_t)(row0 + 16 * mf + (lane & 15)) * a.lda + 32 * ks + 8 * (lane >> 4)),
+                                         (__attribute__((address_space(3))) void*)(smem + blk * 1024), 16, 0, 0);
+    }
+    // bias / LayerNorm-correction vectors -> LDS (every epilogue reads them from there)
+    {
+        constexpr int NV16 = C::V_TOTAL / 4;                    // 16-byte pieces
+        const float4* src = (const float4*)a.vec;
+        for (int i = w * 64; i < NV16; i += TFM_NW * 64)
+            if (i + lane < NV16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i + lane),
+                                                 (__attribute__((address_space(3))) void*)(smem + C::VEC_OFF + i * 16), 16, 0, 0);
+    }
+    // L2 warm-up.  Every workgroup streams ALL the block's weights (3.3 MB, they fit the XCD's 4 MiB L2), and the workgroups of an
+    // XCD run in step: left to demand loads, every line is an HBM miss for all of them at once.  So the workgroups of an XCD split
+    // the stream: workgroup i of the XCD (workgroups are dealt round-robin, blockIdx / 8 numbers them - a speed assumption only)
+    // touches granule i, i + n, ... once at kernel start (one dword per 64 B, landing in an LDS pad nobody reads).  The same for
+    // what this workgroup reads late and only once: its h0 / x_in residual tiles.
+    {
+        char* pad = smem + C::PF_OFF + w * 256;
+        const int nsl = min(16, max(1, (int)gridDim.x >> 3)), sl = ((int)blockIdx.x >> 3) % nsl;
+        const char* base = (const char*)a.wpk + lane * 64;
+        for (int gi = sl + nsl * w; gi < C::UNITS / 4; gi += nsl * TFM_NW) warm64(base + (size_t)gi * 4096, pad);
+        constexpr int SEG = D * 2 / 64;                          // 64-byte segments per tile row
+        for (int i = lane; i < (TFM_TM / TFM_NW) * SEG; i += 64) {
+            const int rr = (TFM_TM / TFM_NW) * w + i / SEG, sg = i - (i / SEG) * SEG;
+            warm64((const char*)(a.xin + (size_t)(row0 + rr) * a.ldx) + sg * 64, pad);
+            warm64((const char*)(a.h0 + (size_t)(row0 + rr) * a.ldh) + sg * 64, pad);
+        }
+    }
+}
+
+// the program of one wave; NFN = its share of the 16-channel fragments of an N = D product, fr0 = the first of them.
 template <int D, int NFN>
 __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const int w, const int lane, const int fr0) {
     using C = TfmCfg<D>;
@@ -169,13 +256,26 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
     char* const bufG1 = smem + 2 * C::BUF;
     float2* const st1 = (float2*)(smem + 2 * C::BUF + C::GBUF);
     float2* const st2 = st1 + TFM_NW * TFM_TM;
-    const bf16x8* const wp = a.wpk + lane;
-    const float* const vec = a.vec;
+    const float* const vec = (const float*)(smem + C::VEC_OFF);          // the bias / LayerNorm-correction vectors, staged at kernel start
     const int xs = C::KSD * 1024;
+    const unsigned lo = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wpk, (unsigned)C::UNITS * 1024u);
+    const WStream w_o1{wrs, (C::OFF_O1 + C::KSD * fr0) * 1024}, w_q{wrs, (C::OFF_Q + C::KSD * fr0) * 1024};
+    const WStream w_o2{wrs, (C::OFF_O2 + C::KSD * fr0) * 1024}, w_m{wrs, (C::OFF_M + C::KSM * fr0) * 1024};
+    const WStream w_g{wrs, (C::OFF_G + w * 4 * C::KSD) * 1024};                   // + chunk * G_CHUNK
+    constexpr int G_CHUNK = TFM_NW * 4 * C::KSD * 1024;
+    auto at = [](const WStream& b, int bytes) { return WStream{b.rs, b.off + bytes}; };
 
     // address pieces of this lane's epilogue word: fragment fr -> channels 16 fr + 4 g .. + 3 of token 16 mf + r
     auto out_off = [&](int mf, int fr) { return lds_chunk(mf, 2 * fr + (g >> 1), r, C::KSD) + (g & 1) * 8; };
 
+    TFM_STAMP(0);
+    Ring<NFN> ring0, ring1;
+    ring_fill<NFN>(ring0, w_o1, lo);                       // the first k-steps of attn1.to_out's weights: in flight under the prologue
+    tfm_prologue<D>(a, smem, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the a1 tile and the vectors have landed in LDS (LDS-DMA completes on vmcnt)
+    __syncthreads();
+    TFM_STAMP(1);
     // ---- S1: h1 = attn1.to_out(a1) + h0 -> bufB, row statistics -> st1 -------------------------------------------------
     {
         U16x4 res[NFN][TFM_MF];
@@ -186,15 +286,14 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
                 res[f][mf] = *(const U16x4*)(a.h0 + (size_t)(row0 + 16 * mf + r) * a.ldh + 16 * (fr0 + f) + 4 * g);
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
-        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O1 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        stage_mm<NFN, C::KSD, true, NFN>(ring0, w_o1, ring1, w_q, lo, bufA + lane * 16, xs, acc);
         TFM_STAMP(2);
         float s[TFM_MF], q[TFM_MF];
 #pragma unroll
         for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
 #pragma unroll
         for (int f = 0; f < NFN; ++f) {
-            const float4 bb = *(const float4*)(vec + C::V_BO1 + 16 * (fr0 + f) + 4 * g);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+            float bv[4]; ld4(vec + C::V_BO1 + 16 * (fr0 + f) + 4 * g, bv);
 #pragma unroll
             for (int mf = 0; mf < TFM_MF; ++mf) {
                 U16x4 o;
@@ -210,6 +309,13 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
         TFM_STAMP(3);
         put_stats(s, q, st1, w, r, g);
     }
+    // context K / V of this wave's head, in operand order: in flight under S2
+    bf16x8 kf[TFM_KF][C::KSQ];
+    const WStream kv{make_rsrc((const char*)a.kvp + (size_t)(row0 / a.T) * C::HEADS * C::KV_UNITS * 1024, C::HEADS * C::KV_UNITS * 1024u), w * C::KV_UNITS * 1024};
+#pragma unroll
+    for (int i = 0; i < TFM_KF; ++i)
+#pragma unroll
+        for (int ks = 0; ks < C::KSQ; ++ks) kf[i][ks] = ldw(kv, lo, i * C::KSQ + ks);
     __syncthreads();
     TFM_STAMP(4);
 
@@ -219,13 +325,12 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
         get_stats<D>(st1, r, mean, rstd);
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
-        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_Q + C::KSD * fr0) * 64, bufB + lane * 16, xs, acc);
+        stage_mm<NFN, C::KSD, true, NFN>(ring1, w_q, ring0, w_o2, lo, bufB + lane * 16, xs, acc);
         TFM_STAMP(5);
 #pragma unroll
         for (int f = 0; f < NFN; ++f) {
-            const float4 ss = *(const float4*)(vec + C::V_SQ + 16 * (fr0 + f) + 4 * g);
-            const float4 bb = *(const float4*)(vec + C::V_BQ + 16 * (fr0 + f) + 4 * g);
-            const float sv[4] = {ss.x, ss.y, ss.z, ss.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+            float sv[4], bv[4];
+            ld4(vec + C::V_SQ + 16 * (fr0 + f) + 4 * g, sv); ld4(vec + C::V_BQ + 16 * (fr0 + f) + 4 * g, bv);
 #pragma unroll
             for (int mf = 0; mf < TFM_MF; ++mf) {
                 U16x4 o;
@@ -241,17 +346,11 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
 
     // ---- S3: cross-attention over the cached context, wave = head; a2 overwrites q in place --------------------------
     {
-        const int b = row0 / a.T;
-        const bf16x8* kv = a.kvp + ((size_t)(b * C::HEADS + w) * C::KV_UNITS) * 64 + lane;
-        bf16x8 kf[TFM_KF][C::KSQ], vf[C::MD][TFM_PVS];
-#pragma unroll
-        for (int i = 0; i < TFM_KF; ++i)
-#pragma unroll
-            for (int ks = 0; ks < C::KSQ; ++ks) kf[i][ks] = kv[(i * C::KSQ + ks) * 64];
+        bf16x8 vf[C::MD][TFM_PVS];                      // (V: needed after the first softmax)
 #pragma unroll
         for (int md = 0; md < C::MD; ++md)
 #pragma unroll
-            for (int s = 0; s < TFM_PVS; ++s) vf[md][s] = kv[(TFM_KF * C::KSQ + md * TFM_PVS + s) * 64];
+            for (int s = 0; s < TFM_PVS; ++s) vf[md][s] = ldw(kv, lo, TFM_KF * C::KSQ + md * TFM_PVS + s);
         const int c0 = (C::DH / 8) * w;                 // first 8-channel group of this head
 #pragma unroll 1
         for (int qf = 0; qf < TFM_MF; ++qf) {
@@ -330,18 +429,18 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
     TFM_STAMP(9);
 
     // ---- S4: h2 = attn2.to_out(a2) + h1 -> bufB in place, row statistics -> st2 ----------------------------------------
+    Ring<4> ringG;
     {
         f32x4 acc[NFN][TFM_MF];
         zero_acc<NFN>(acc);
-        stage_mm<NFN, C::KSD>(wp + (size_t)(C::OFF_O2 + C::KSD * fr0) * 64, bufA + lane * 16, xs, acc);
+        stage_mm<NFN, C::KSD, true, 4>(ring0, w_o2, ringG, w_g, lo, bufA + lane * 16, xs, acc);
         TFM_STAMP(10);
         float s[TFM_MF], q[TFM_MF];
 #pragma unroll
         for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
 #pragma unroll
         for (int f = 0; f < NFN; ++f) {
-            const float4 bb = *(const float4*)(vec + C::V_BO2 + 16 * (fr0 + f) + 4 * g);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+            float bv[4]; ld4(vec + C::V_BO2 + 16 * (fr0 + f) + 4 * g, bv);
 #pragma unroll
             for (int mf = 0; mf < TFM_MF; ++mf) {
                 char* const p = bufB + out_off(mf, fr0 + f);
@@ -366,25 +465,23 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
     f32x4 accF[NFN][TFM_MF];
     zero_acc<NFN>(accF);
     {
-        float mean[TFM_MF], rstd[TFM_MF];
-        get_stats<D>(st2, r, mean, rstd);
-        const bf16x8* const wm = wp + (size_t)(C::OFF_M + C::KSM * fr0) * 64;
 #pragma unroll 1
         for (int c = 0; c < C::NCH; ++c) {
             char* const G = (c & 1) ? bufG1 : bufA;
+            const WStream wmc = at(w_m, c * TFM_GKS * NFN * 1024);
             {
                 f32x4 acc[4][TFM_MF];
                 zero_acc<4>(acc);
-                stage_mm<4, C::KSD>(wp + (size_t)(C::OFF_G + (c * TFM_NW + w) * 4 * C::KSD) * 64, bufB + lane * 16, xs, acc);
+                stage_mm<4, C::KSD, true, NFN>(ringG, at(w_g, c * G_CHUNK), ring1, wmc, lo, bufB + lane * 16, xs, acc);
                 if (c == 1) TFM_STAMP(13);
+                float mean[TFM_MF], rstd[TFM_MF];               // (re-derived per chunk from the LDS partials: 8 registers fewer across the k-loops)
+                get_stats<D>(st2, r, mean, rstd);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int col = 16 * (2 * w + p) + 4 * g;           // column inside the chunk
                     const int j0 = TFM_CH * c + col;                    // GEGLU output column
-                    const float4 sv4 = *(const float4*)(vec + C::V_SV + j0), bv4 = *(const float4*)(vec + C::V_BV + j0);
-                    const float4 sg4 = *(const float4*)(vec + C::V_SG + j0), bg4 = *(const float4*)(vec + C::V_BG + j0);
-                    const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-                    const float sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w}, bg[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
+                    float sv[4], bv[4], sg[4], bg[4];
+                    ld4(vec + C::V_SV + j0, sv); ld4(vec + C::V_BV + j0, bv); ld4(vec + C::V_SG + j0, sg); ld4(vec + C::V_BG + j0, bg);
 #pragma unroll
                     for (int mf = 0; mf < TFM_MF; ++mf) {
                         U16x4 o;
@@ -401,12 +498,16 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
             if (c == 1) TFM_STAMP(14);
             __syncthreads();
             if (c == 1) TFM_STAMP(15);
-            stage_mm<NFN, TFM_GKS>(wm + (size_t)(c * TFM_GKS * NFN) * 64, G + lane * 16, TFM_GKS * 1024, accF);
+            // (after the last chunk the ring of the GEGLU stream is refilled with that chunk's first k-steps again: never used)
+            const int cn = c + 1 < C::NCH ? c + 1 : c;
+            stage_mm<NFN, TFM_GKS, true, 4>(ring1, wmc, ringG, at(w_g, cn * G_CHUNK), lo, G + lane * 16, TFM_GKS * 1024, accF);
             if (c == 1) TFM_STAMP(16);
             if (c == C::NCH - 1) TFM_STAMP(17);
         }
         // the h2 part of the merged GEMM (K columns 4d .. 5d)
-        stage_mm<NFN, C::KSD>(wm + (size_t)(C::NCH * TFM_GKS * NFN) * 64, bufB + lane * 16, xs, accF);
+        const WStream wt = at(w_m, C::NCH * TFM_GKS * NFN * 1024);
+        ring_fill<NFN>(ring1, wt, lo);
+        stage_mm<NFN, C::KSD, false, NFN>(ring1, wt, ring1, wt, lo, bufB + lane * 16, xs, accF);
         TFM_STAMP(18);
     }
 
@@ -414,8 +515,7 @@ __device__ __forceinline__ void tfm_wave(const TfmTailArgs& a, char* smem, const
 #pragma unroll
     for (int f = 0; f < NFN; ++f) {
         const int n = 16 * (fr0 + f) + 4 * g;
-        const float4 bb = *(const float4*)(vec + C::V_BM + n);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        float bv[4]; ld4(vec + C::V_BM + n, bv);
 #pragma unroll
         for (int mf = 0; mf < TFM_MF; ++mf) {
             const size_t row = (size_t)(row0 + 16 * mf + r);
@@ -433,37 +533,8 @@ template <int D>
 __global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs a) {
     using C = TfmCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // L2 warm-up.  Every workgroup streams ALL the block's weights (3.3 MB, they fit the XCD's 4 MiB L2), and the workgroups of an
-    // XCD run in step: left to demand loads, every line is an HBM miss for all of them at once and the kernel runs at
-    // (bytes in flight per workgroup) / (HBM latency).  So the workgroups of an XCD split the stream: workgroup i of the XCD
-    // (workgroups are dealt round-robin, blockIdx / 8 numbers them - a speed assumption only) touches granule i, i + n, ... once at
-    // kernel start (one dword per 64 B, landing in an LDS pad nobody reads); the demand loads then find L2 hits.
-    {
-        const int nsl = min(16, max(1, (int)gridDim.x >> 3)), sl = ((int)blockIdx.x >> 3) % nsl;
-        const char* base = (const char*)a.wpk + lane * 64;
-        char* pad = smem + C::PF_OFF + w * 256;
-        for (int gi = sl + nsl * w; gi < C::UNITS / 4; gi += nsl * TFM_NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)gi * 4096),
-                                             (__attribute__((address_space(3))) void*)pad, 4, 0, 0);
-    }
-    TFM_STAMP(0);
-    // a1 tile -> bufA in operand order: 1 KiB block (mf, ks) = 64 lanes x 16 B, lane (g, r) holds a1[16 mf + r][32 ks + 8 g ..]
-    {
-        const int row0 = blockIdx.x * TFM_TM;
-        constexpr int PER = TFM_MF * C::KSD / TFM_NW;
-        static_assert(TFM_MF * C::KSD % TFM_NW == 0, "a1 tile blocks per wave");
-        U16x8 t[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int blk = w + i * TFM_NW, mf = blk / C::KSD, ks = blk - mf * C::KSD;
-            t[i] = *(const U16x8*)(a.a1 + (size_t)(row0 + 16 * mf + (lane & 15)) * a.lda + 32 * ks + 8 * (lane >> 4));
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) *(U16x8*)(smem + ((w + i * TFM_NW) * 64 + lane) * 16) = t[i];
-    }
-    __syncthreads();
-    TFM_STAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keeps every per-wave offset in SGPRs
     if (C::NWA == TFM_NW || w < C::NWA) tfm_wave<D, C::NFA>(a, smem, w, lane, w * C::NFA);
     else tfm_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
 }

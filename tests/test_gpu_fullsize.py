@@ -368,4 +368,5 @@ def test_full_size_grouped_encoder_equals_two_chains_bit_for_bit(monkeypatch):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]), 'the XCD-aware tile order of the weight-heavy layers changed a bit'
     print(f'launches per step at batch 8: two chains {res[0][2]}, grouped {res[1][2]}')
-    assert res[1][2] <= res[0][2] - 140
+    # (round 4: the d = 320 blocks' row-local tail is ONE launch in both plans - kernels_tfm.hip - so pairing saves 130, not 146)
+    assert res[1][2] <= res[0][2] - 120
