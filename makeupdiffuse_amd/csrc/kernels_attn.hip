@@ -27,13 +27,21 @@ namespace {
 #define MKD_ATTN_TAIL 1
 #endif
 
-template <int DH, int KT>
+template <int DH, int KT, int MSUM = 0>
 struct AttnCfg {
     static constexpr int TAIL = ((MKD_ATTN_TAIL == 2 || (MKD_ATTN_TAIL == 1 && KT == 96)) && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
     static constexpr int KS = TAIL ? DH / 32 : (DH + 31) / 32;          // 32-deep k-steps of QK^T
     static constexpr int DHP = 32 * KS + 16 * TAIL;      // QK^T contraction depth, zero padded (40 -> 48, not 64)
     static constexpr int DVP = (DH + 15) / 16 * 16;      // output rows of O^T (padded)
     static constexpr int MD = DVP / 16;                  // O^T fragments
+    // Row sums of P on the matrix cores (MSUM): when the padded V tile has a spare column (dh = 40 -> 48), column DH holds 1.0 for
+    // every valid key, so row DH of O^T = V^T P^T accumulates sum_key bf16(p) - the softmax denominator - inside the P.V MFMAs that
+    // run anyway: 16 v_add_f32 per tile leave a VALU-bound loop (rocprofv3, 4096 keys: the SIMDs' vector ALUs are busy 65-70 % of the
+    // kernel, the matrix cores 26 %: profiles/exp_r4_attn_pmc_*.csv), and the denominator is the sum of exactly the rounded weights
+    // the numerator uses.  The running rescale of O rescales it with the rest.  Chosen by the launcher for >= 2048 keys (dh 40,
+    // 4096 keys: 445 -> 427 us).  Also tried in round 4 and dropped: two K/V tile buffers with ONE barrier per tile (+7 % at dh 40,
+    // equal at dh 80).
+    static constexpr int ONES = (MSUM && DVP > DH) ? 1 : 0;
     static constexpr int KROW = DHP * 2 + 16;            // K tile row stride in bytes (pad: bank spread)
     // V tile stays ROW-MAJOR [key][d] and is read transposed by ds_read_b64_tr_b16 (gfx950).  A 32-lane half reads 8
     // consecutive key rows x 4 column quads: conflict-free when the row stride in dwords is 8 * odd.
@@ -47,13 +55,13 @@ struct AttnCfg {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-template <int DH, int NW, int KT>
+template <int DH, int NW, int KT, int MSUM = 0>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> io, int ldq, int ldk, int ldv, int ldo,
                                                         int Tq, int Tk, int heads, float scale_log2e, int causal) {
     // grouped launch: grid z selects the problem (same geometry, own tensors)
     const bf16_t* __restrict__ const Q = io.g[blockIdx.z].q; const bf16_t* __restrict__ const K = io.g[blockIdx.z].k;
     const bf16_t* __restrict__ const V = io.g[blockIdx.z].v; bf16_t* __restrict__ const O = io.g[blockIdx.z].o;
-    using C = AttnCfg<DH, KT>;
+    using C = AttnCfg<DH, KT, MSUM>;
     static_assert(KT % 32 == 0, "key tile: whole 32-key PV steps");
     constexpr int KB = KT / 16;          // 16-key blocks of S^T
     extern __shared__ __attribute__((aligned(16))) char smem[];        // C::KBYTES + C::VBYTES (66 KB for dh 160 with 96-key tiles)
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
 #pragma unroll
             for (int j = 0; j < 8; ++j) d.v[j] = 0;
             if (idx < VCHUNKS && key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(vbase + (size_t)(key0 + r) * ldv + c * 8);
+            if (C::ONES && idx < VCHUNKS && key0 + r < Tk && c * 8 == DH) d.v[0] = 0x3F80;       // bf16 1.0 in column DH
             vreg[i] = d;
         }
     };
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
             for (int r = 0; r < 4; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mf][r], scale_log2e, -m_new));
                 st[mf][r] = pv;
-                psum += pv;
+                if (!C::ONES) psum += pv;
             }
         if (__any(m_new != m_run)) {                           // wave-uniform: after the first tiles the max rarely moves
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -238,8 +247,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         }
     }
 
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    if (C::ONES) {
+        l_run = __shfl(oacc[DH / 16][DH % 4], 16 * ((DH % 16) / 4) + qc, 64);      // row DH of O^T: lane group (DH % 16) / 4, register DH % 4
+    } else {
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_run;
     if (qi < Tq) {
         bf16_t* orow = O + ((size_t)b * Tq + qi) * ldo + h * DH;
@@ -270,25 +283,30 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
     static const bool kt96 = !(getenv("MKD_ATTN_KT96") && atoi(getenv("MKD_ATTN_KT96")) == 0);      // (A/B knob)
     const bool one96 = kt96 && !wide && !causal && Tk > 64 && Tk <= 96;      // cross-attention (77 context keys): one 96-key tile
+#ifndef MKD_ATTN_MSUM_MIN
+#define MKD_ATTN_MSUM_MIN 2048
+#endif
+    const bool msum = wide && Tk >= MKD_ATTN_MSUM_MIN && !causal;         // softmax denominators on the matrix cores (AttnCfg::ONES) where it measured faster
     const int qb = wide ? 128 : 64;
     dim3 grid((Tq + qb - 1) / qb, batch * heads, second ? 2 : 1);
-#define MKD_ATTN_LAUNCH(D, NWV, KTV)                                                                          \
+#define MKD_ATTN_LAUNCH(D, NWV, KTV, MS)                                                                      \
     do {                                                                                                      \
         constexpr int lds = AttnCfg<D, KTV>::KBYTES + AttnCfg<D, KTV>::VBYTES;                                  \
         static bool attr = false;                                                                             \
         if (lds > 64 * 1024 && !attr) {                                                                       \
-            hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<D, NWV, KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipError_t e = hipFuncSetAttribute((const void*)attention_kernel<D, NWV, KTV, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(attention LDS): ") + hipGetErrorString(e));            \
             attr = true;                                                                                      \
         }                                                                                                     \
-        hipLaunchKernelGGL((attention_kernel<D, NWV, KTV>), grid, dim3(64 * NWV), lds, stream, io, ldq, ldk, ldv, ldo, Tq, Tk,     \
+        hipLaunchKernelGGL((attention_kernel<D, NWV, KTV, MS>), grid, dim3(64 * NWV), lds, stream, io, ldq, ldk, ldv, ldo, Tq, Tk,     \
                            heads, sl, causal);                                                                \
     } while (0)
 #define MKD_ATTN_CASE(D)                                                                                      \
     case D:                                                                                                   \
-        if (wide) MKD_ATTN_LAUNCH(D, 8, 64);                                                                  \
-        else if (one96) MKD_ATTN_LAUNCH(D, 4, 96);                                                            \
-        else MKD_ATTN_LAUNCH(D, 4, 64);                                                                       \
+        if (wide && msum) MKD_ATTN_LAUNCH(D, 8, 64, 1);                                                       \
+        else if (wide) MKD_ATTN_LAUNCH(D, 8, 64, 0);                                                          \
+        else if (one96) MKD_ATTN_LAUNCH(D, 4, 96, 0);                                                         \
+        else MKD_ATTN_LAUNCH(D, 4, 64, 0);                                                                    \
         break;
     switch (dh) {
         MKD_ATTN_CASE(8)

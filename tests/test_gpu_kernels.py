@@ -312,6 +312,26 @@ def test_attention(B, Tq, Tk, heads, dh):
     assert_close_bf16(o, ref, rel=8e-3, what='attention')
 
 
+def test_attention_row_sums_on_the_matrix_cores():
+    """Round 4: for >= 2048 keys at dh 40 the softmax denominator is row DH of O^T = V^T P^T (a column of ones in the padded V tile)
+    instead of 16 VALU adds per tile.  4096 / 2304 (ragged last tile) keys against torch, plus a spiked key in a late tile (rescale
+    path: the denominator row is rescaled with the rest of O)."""
+    lib = L()
+    for (B, Tq, Tk, heads) in ((1, 1024, 4096, 2), (2, 1152, 2304, 1)):
+        dh = 40; d = heads * dh
+        g = torch.Generator().manual_seed(Tk)
+        q = torch.randn(B * Tq, d, generator=g); k = torch.randn(B * Tk, d, generator=g); v = torch.randn(B * Tk, d, generator=g)
+        k[Tk - 100, :dh] = q[7, :dh] * 4.0                         # sample 0, head 0: query 7 meets its spike in the last tiles
+        q, k, v = bf(q), bf(k), bf(v)
+        o = torch.zeros(B * Tq, d, device=DEV, dtype=torch.bfloat16)
+        assert lib.mkd_attention(P(q), d, P(k), d, P(v), d, P(o), d, B, Tq, Tk, heads, dh, dh ** -0.5, None) == 0, lib.mkd_last_error()
+        sync()
+        qf = q.float().view(B, Tq, heads, dh).transpose(1, 2); kf = k.float().view(B, Tk, heads, dh).transpose(1, 2)
+        vf = v.float().view(B, Tk, heads, dh).transpose(1, 2)
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) * dh ** -0.5, -1) @ vf).transpose(1, 2).reshape(B * Tq, d)
+        assert_close_bf16(o, ref, rel=8e-3, what=f'attention, MFMA row sums, {Tk} keys')
+
+
 def test_attention_spiked_scores():
     """online-softmax rescale path: one key far above the rest, placed in a late tile."""
     lib = L()
