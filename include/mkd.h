@@ -76,6 +76,21 @@ int mkd_param_total(const mkd_ctx* ctx);
 const char* mkd_param_name(const mkd_ctx* ctx, int index);
 int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
 
+/* Per-context plan switches (round 4: what used to be read from MKD_* environment variables once per process; the variables still
+ * give the initial values).  Takes effect at the next mkd_prepare (the launch plan is re-built).  Names:
+ *   "tfm_tail"             fused row-local transformer tail: 0 off, 1 wherever the kernel covers the shape, -1 shape policy (default)
+ *   "tfm_tail_min_rows"    ... the policy's threshold on the rows (samples x tokens) of a block (default 4096)
+ *   "gn_2k_min_hw"         GroupNorm over >= this many pixels per sample: two full-chip launches (default 4096)
+ *   "xcd_auto_ratio"       XCD-aware tile order where M <= ratio x N (default 1; 0 = launch order everywhere)
+ *   "dec_lanes"            decoder batch lanes 0 / 2 / 4 (default 2)
+ *   "ln_fly"               bit mask: LayerNorm taken on the fly by 1 = q|k|v, 2 = attn2.to_q, 4 = GEGLU projection (default 2)
+ *   "gn_slab_min_channels" slab-fed GroupNorm from this many channels (default 1280)
+ *   "graph_steps"          DDIM steps per captured graph (default 5)
+ * Unknown names return MKD_ERR_ARG.  The tile tuner's state (mkd_gemm_force_tile / _set_xcd_mode / _set_override) stays process-global
+ * and is refused (MKD_ERR_STATE) for non-default values while more than one context is alive. */
+int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value);
+int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value);
+
 /* ---- conditioning ----------------------------------------------------------------------- */
 /* Binds the step-invariant conditioning for a batch (cond dict of makeup_diffuse.py:42-57,
  * 152-166): hint = cat(c_concat,1) [B,hint_channels,8h,8w] in [0,1]; context = cat(c_crossattn,1)
@@ -269,6 +284,8 @@ int  mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, 
                          const float* ff0_w, const float* ff0_b, const float* ff2_w, const float* ff2_b, const float* proj_out_w,
                          const float* proj_out_b, mkd_tfm_tail** out);
 void mkd_tfm_tail_destroy(mkd_tfm_tail* h);
+/* Experiment builds (-DMKD_TFM_TRACE) only: device buffer [workgroups][8][32] of int64 time stamps; a no-op in the product build. */
+int  mkd_debug_tfm_trace(long long* buf);
 int  mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream);
 int  mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_t* h0, int ldh, const uint16_t* xin, int ldx,
                       uint16_t* out, int ldo, int M, int T, void* stream);

@@ -221,6 +221,13 @@ struct mkd_ctx {
     bool dec_overlap = getenv("MKD_DEC_OVERLAP") ? atoi(getenv("MKD_DEC_OVERLAP")) != 0 : true;
     bool capturing = false;
     int plan_epoch = 0;
+    int opt_epoch = 0, opt_epoch_planned = 0;      // bumped by mkd_ctx_set_option: the next mkd_prepare re-plans
+    int graph_steps = getenv("MKD_GRAPH_STEPS") ? atoi(getenv("MKD_GRAPH_STEPS")) : 5;      // DDIM steps per captured graph
+    // Shape policy (round 4, profiles/exp_r4_bigcfg_switches.txt): a GroupNorm over >= gn_2k_min_hw pixels per sample runs as the two
+    // full-chip launches (statistics, apply) instead of the single launch that keeps a (sample, group chunk) slab in registers on
+    // 32-128 workgroups: at 64x64 latents (512x512 images) the single launch holds too few CUs for too long (16.51 -> 16.26 ms per
+    // evaluation); at 32x32 it is the other way round (8.36 -> 8.63 ms with guidance), so the rule is by tensor size.
+    int gn_2k_min_hw = getenv("MKD_GN_2K_MINHW") ? atoi(getenv("MKD_GN_2K_MINHW")) : 4096;
     size_t persist_eps_begin = 0;
     std::vector<hipEvent_t> aux_ev; int aux_used = 0;        // cross-stream edges inside the decoder (re-used across plan rebuilds)
     std::vector<Op> plan_prepare, plan_eps;
@@ -657,7 +664,8 @@ struct mkd_ctx {
     // (tools/exp_r3_xcd_auto.sh): off 5.604 / 5.610, ratio 1 5.557 / 5.549, 2 5.547 / 5.548, 4 5.557 / 5.579, 8 5.570 / 5.564, 16 5.637 /
     // 5.648 (= mode 1 everywhere, MKD_XCD_MODE=1: 5.645); by M alone (N >= 640): M <= 512 5.576 / 5.564, <= 2048 5.565 / 5.544.
     // Results do not depend on the order (bit-identical: test_xcd_auto_order_changes_no_bit).
-    float xcd_auto_ratio = getenv("MKD_XCD_AUTO_RATIO") ? (float)atof(getenv("MKD_XCD_AUTO_RATIO")) : 2.0f;
+    // round 4: default 1 (was 2): equal at batch 8 / guidance / interpolation, +0.8 % at 512x512 (profiles/exp_r4_bigcfg_switches.txt, exp_r3_xcd_configs.txt)
+    float xcd_auto_ratio = getenv("MKD_XCD_AUTO_RATIO") ? (float)atof(getenv("MKD_XCD_AUTO_RATIO")) : 1.0f;
     void op_gemm(GemmArgs a, int force_splitk = 0) {
         a.zero = zero_page;
         a.splitk = force_splitk;
@@ -753,7 +761,7 @@ struct mkd_ctx {
         Tensor t = in;
         const int sid = cur_sid;
         push(*cur_plan, [self, t, gamma, beta, eps, silu, out, ld_out, sid](hipStream_t st) {
-            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[arena_of(sid)], st);
+            return launch_groupnorm(t.p, t.ld, gamma, beta, eps, silu, out, ld_out, t.B, t.H * t.W, t.C, 32, self->gn_ws[arena_of(sid)], st, nullptr, self->gn_2k_min_hw);
         }, 1, 0.0, K_GROUPNORM, "B=" + std::to_string(in.B) + " HW=" + std::to_string(in.H * in.W) + " C=" + std::to_string(in.C));
         OpDesc& d = last_desc(); d.type = D_GN; d.sid = sid; d.nio = NormIo{in.p, out, gamma, beta}; d.eps = eps; d.silu = silu;
         d.ld_in = in.ld; d.ld_out = ld_out; d.nb = in.B; d.hw = in.H * in.W; d.C = in.C;
@@ -1436,7 +1444,7 @@ struct mkd_ctx {
                 const OpDesc dx = x, dy = y;
                 fn = [self, dx, dy](hipStream_t st) {
                     return launch_groupnorm(dx.nio.x, dx.ld_in, dx.nio.gamma, dx.nio.beta, dx.eps, dx.silu, dx.nio.y, dx.ld_out, dx.nb, dx.hw, dx.C, 32,
-                                            self->gn_ws[arena_of(dx.sid)], st, &dy.nio);
+                                            self->gn_ws[arena_of(dx.sid)], st, &dy.nio, self->gn_2k_min_hw);
                 };
                 break;
             }
@@ -1493,12 +1501,12 @@ struct mkd_ctx {
         const bool interp = hint2 != nullptr;
         if (interp && (!ctrl || !alpha)) return mkd_fail(MKD_ERR_ARG, "mkd_prepare_interp: needs hint, hint2 and alpha");
         const bool same = prepared && batch == B && hh == h && ww == w && ctrl == has_control && (only_mid_control != 0) == only_mid &&
-                          interp == has_interp && plan_epoch == gemm_plan_epoch();
+                          interp == has_interp && plan_epoch == gemm_plan_epoch() && opt_epoch_planned == opt_epoch;
         bool same_scales = same;
         for (int i = 0; i < n_ctrl() && same_scales; ++i) same_scales = scales[i] == (control_scales ? control_scales[i] : 1.f);
         in_hint = hint; in_context = context; in_hint2 = hint2; in_alpha = alpha;
         if (!same_scales) {
-            plan_epoch = gemm_plan_epoch();
+            plan_epoch = gemm_plan_epoch(); opt_epoch_planned = opt_epoch;
             B = batch; h = hh; w = ww; has_control = ctrl; only_mid = only_mid_control != 0; has_interp = interp;
             for (int i = 0; i < n_ctrl(); ++i) scales[i] = control_scales ? control_scales[i] : 1.f;
             prepared = false;
@@ -1861,7 +1869,7 @@ struct mkd_ctx {
             // MKD_GRAPH_STEPS = k > 1: k consecutive steps captured as ONE graph (the step reads its index from the device-resident
             // counter, so the same capture repeated k times is k different steps); the remainder runs on the single-step graph
             // (default 5: a graph boundary costs ~30 us; batch 8: 5.85 -> 5.82 ms per evaluation, batch 1: 2.99 -> 2.97)
-            static const int gsteps = getenv("MKD_GRAPH_STEPS") ? atoi(getenv("MKD_GRAPH_STEPS")) : 5;
+            const int gsteps = graph_steps;
             int done = 0;
             if (gsteps > 1 && n_steps >= gsteps) {
                 if (!multi_graph || multi_graph_steps != gsteps) {
@@ -2317,6 +2325,8 @@ static thread_local std::string g_last_error;
 void mkd_set_error(const std::string& msg) { g_last_error = msg; }
 int mkd_fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 
+static int g_live_contexts = 0;
+
 extern "C" {
 
 const char* mkd_last_error(void) { return g_last_error.c_str(); }
@@ -2352,10 +2362,11 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
     if (const char* sc = getenv("MKD_SPLITK_CAP")) gemm_set_splitk_cap(atoi(sc));
     c->build_param_spec();
     *out = c;
+    ++g_live_contexts;
     return 0;
 }
 
-void mkd_ctx_destroy(mkd_ctx* ctx) { delete ctx; }
+void mkd_ctx_destroy(mkd_ctx* ctx) { if (ctx) { --g_live_contexts; delete ctx; } }
 
 int mkd_load_weight(mkd_ctx* ctx, const char* name, const float* data, int ndim, const int64_t* shape) {
     if (!ctx || !name || !data || !shape) return mkd_fail(MKD_ERR_ARG, "mkd_load_weight: null argument");
@@ -2414,10 +2425,49 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
     return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
                        (hipStream_t)stream);
 }
-int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
-int mkd_gemm_set_xcd_mode(int mode) { gemm_set_xcd_mode(mode); return 0; }
+// The tile tuner's state (forced tile, XCD mode, per-shape overrides) is PROCESS-global: it belongs to the single-kernel entries and to
+// the tuners, which drive one context.  With more than one live context a non-default setting would silently re-plan all of them:
+// refused (per-context plan switches: mkd_ctx_set_option).
+static int tuner_guard(bool non_default, const char* what) {
+    if (non_default && g_live_contexts > 1)
+        return mkd_fail(MKD_ERR_STATE, std::string(what) + ": process-global tuner state with " + std::to_string(g_live_contexts) + " live contexts (use mkd_ctx_set_option)");
+    return 0;
+}
+int mkd_gemm_force_tile(int cfg) { int rc = tuner_guard(cfg >= 0, "mkd_gemm_force_tile"); if (rc) return rc; gemm_force_tile_cfg(cfg); return 0; }
+int mkd_gemm_set_xcd_mode(int mode) { int rc = tuner_guard(mode != 0, "mkd_gemm_set_xcd_mode"); if (rc) return rc; gemm_set_xcd_mode(mode); return 0; }
 int mkd_debug_poison(mkd_ctx* ctx) { return ctx ? ctx->debug_poison() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
+int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value) {
+    if (!ctx || !name) return mkd_fail(MKD_ERR_ARG, "mkd_ctx_set_option: null argument");
+    const std::string n(name);
+    const int iv = (int)value;
+    if (n == "tfm_tail") ctx->tfm_tail = iv;
+    else if (n == "tfm_tail_min_rows") ctx->tfm_tail_min_rows = iv;
+    else if (n == "gn_2k_min_hw") ctx->gn_2k_min_hw = iv;
+    else if (n == "xcd_auto_ratio") ctx->xcd_auto_ratio = (float)value;
+    else if (n == "dec_lanes") { if (iv != 0 && iv != 2 && iv != 4) return mkd_fail(MKD_ERR_ARG, "dec_lanes: 0, 2 or 4"); ctx->dec_lanes = iv; }
+    else if (n == "ln_fly") ctx->ln_fly = iv & 7;
+    else if (n == "gn_slab_min_channels") ctx->gn_slab_minc = iv;
+    else if (n == "graph_steps") { if (iv < 1) return mkd_fail(MKD_ERR_ARG, "graph_steps >= 1"); ctx->graph_steps = iv; ctx->drop_graph(); return 0; }
+    else return mkd_fail(MKD_ERR_ARG, "mkd_ctx_set_option: unknown option '" + n + "'");
+    ++ctx->opt_epoch;
+    return 0;
+}
+int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value) {
+    if (!ctx || !name || !value) return mkd_fail(MKD_ERR_ARG, "mkd_ctx_get_option: null argument");
+    const std::string n(name);
+    if (n == "tfm_tail") *value = ctx->tfm_tail;
+    else if (n == "tfm_tail_min_rows") *value = ctx->tfm_tail_min_rows;
+    else if (n == "gn_2k_min_hw") *value = ctx->gn_2k_min_hw;
+    else if (n == "xcd_auto_ratio") *value = ctx->xcd_auto_ratio;
+    else if (n == "dec_lanes") *value = ctx->dec_lanes;
+    else if (n == "ln_fly") *value = ctx->ln_fly;
+    else if (n == "gn_slab_min_channels") *value = ctx->gn_slab_minc;
+    else if (n == "graph_steps") *value = ctx->graph_steps;
+    else return mkd_fail(MKD_ERR_ARG, "mkd_ctx_get_option: unknown option '" + n + "'");
+    return 0;
+}
 int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk) {
+    { int rc = tuner_guard(M > 0 && cfg >= 0, "mkd_gemm_set_override"); if (rc) return rc; }
     gemm_set_override(M, N, K, conv3x3, stride, up, cfg, splitk);
     return 0;
 }

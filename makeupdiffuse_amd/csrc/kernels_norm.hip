@@ -655,7 +655,7 @@ size_t groupnorm_partials_bytes(int batch, int hw, int groups) {
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
-                     hipStream_t stream, const NormIo* second) {
+                     hipStream_t stream, const NormIo* second, int two_kernel_min_hw) {
     if (C % 8 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C, ld must be multiples of 8");
     Pair<NormIo> io;
     io.g[0] = NormIo{x, y, gamma, beta};
@@ -671,7 +671,6 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
         if (gpb <= groups) {
             const int nch = gpb * cg;
             const size_t slab = (size_t)hw * nch * sizeof(bf16_t);
-            static const int two_kernel_min_hw = getenv("MKD_GN_2K_MINHW") ? atoi(getenv("MKD_GN_2K_MINHW")) : (1 << 30);    // (A/B knob)
             if (nch / 8 <= 256 && slab <= (size_t)384 * 1024 && hw < two_kernel_min_hw) {   // (V <= 256 <= blockDim)
                 // smallest block (256..1024 threads) whose threads hold their whole share in <= 16 registers-vectors
                 const int V = nch / 8;
@@ -698,9 +697,9 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
         }
     }
     if (second) {          // the two-kernel path is not grouped: one problem after the other (they share the partials workspace)
-        int rc = launch_groupnorm(x, ld_in, gamma, beta, eps, silu, y, ld_out, batch, hw, C, groups, partials, stream, nullptr);
+        int rc = launch_groupnorm(x, ld_in, gamma, beta, eps, silu, y, ld_out, batch, hw, C, groups, partials, stream, nullptr, two_kernel_min_hw);
         if (rc) return rc;
-        return launch_groupnorm(second->x, ld_in, second->gamma, second->beta, eps, silu, second->y, ld_out, batch, hw, C, groups, partials, stream, nullptr);
+        return launch_groupnorm(second->x, ld_in, second->gamma, second->beta, eps, silu, second->y, ld_out, batch, hw, C, groups, partials, stream, nullptr, two_kernel_min_hw);
     }
     const int V = C / 8;
     if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");

@@ -142,7 +142,8 @@ size_t gemm_ws_bytes(int M, int N, int splitk);
 
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
-                     hipStream_t stream, const NormIo* second = nullptr);      // second: same geometry, grouped launch
+                     hipStream_t stream, const NormIo* second = nullptr,       // second: same geometry, grouped launch
+                     int two_kernel_min_hw = 1 << 30);      // >= this many pixels per sample: the two full-chip launches (mkd_ctx::gn_2k_min_hw)
 size_t groupnorm_partials_bytes(int batch, int hw, int groups);
 // GroupNorm with producer-emitted statistics (gstat[batch][32][2] int64 fixed point, see gemm_device.h): element-wise apply,
 // and the stand-alone producer of the same statistics for tensors whose writer cannot emit them

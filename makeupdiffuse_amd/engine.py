@@ -293,6 +293,15 @@ class MkdEngine:
                                                 C.c_void_p(_stream())), 'mkd_clip_encode')
         return out
 
+    def set_option(self, name: str, value: float) -> None:
+        """Per-context plan switch (include/mkd.h: mkd_ctx_set_option); takes effect at the next prepare()."""
+        _lib.check(self.lib.mkd_ctx_set_option(self._ctx, name.encode(), float(value)), f'mkd_ctx_set_option({name})')
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double()
+        _lib.check(self.lib.mkd_ctx_get_option(self._ctx, name.encode(), C.byref(v)), f'mkd_ctx_get_option({name})')
+        return v.value
+
     def debug_poison(self) -> None:
         """Tests only: NaN-fill everything one eps evaluation produces (see mkd_debug_poison)."""
         with torch.cuda.device(self.device):

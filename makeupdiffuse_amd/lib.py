@@ -53,6 +53,9 @@ SIGNATURES = {
     'mkd_param_total': (_I, [_P]),
     'mkd_param_name': (C.c_char_p, [_P, _I]),
     'mkd_param_shape': (_I, [_P, _I, C.POINTER(_L)]),
+    'mkd_ctx_set_option': (_I, [_P, C.c_char_p, C.c_double]),
+    'mkd_ctx_get_option': (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
+    'mkd_debug_tfm_trace': (_I, [_P]),
     'mkd_prepare': (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_prepare_interp': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_eps': (_I, [_P, _P, _P, _P, _P]),

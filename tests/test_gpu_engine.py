@@ -525,3 +525,43 @@ def test_xcd_auto_order_changes_no_bit(monkeypatch):
     check_eps(res['2'][0], torch.cat([G['eps'], G['eps'], G['eps'][:1]]), what='default XCD order')
     for r in ('0', '1e9'):
         assert torch.equal(res[r][0], res['2'][0]) and torch.equal(res[r][1], res['2'][1]), f'MKD_XCD_AUTO_RATIO={r} changed the result'
+
+
+def test_plan_options_are_per_context_and_the_global_tuner_is_guarded():
+    """plan switches live in the context (mkd_ctx_set_option: the next prepare re-plans, another context is not
+    touched); the tile tuner's process-global state is refused for non-default values while two contexts are alive."""
+    import ctypes as C
+    from makeupdiffuse_amd import lib as mlib
+    e1 = MkdEngine(NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+                             hint_widths=(16, 16, 32, 32, 32, 32, 64)))
+    e1.init_random(3, norm_jitter=0.2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 4, 16, 16, generator=g); hint = torch.rand(4, 6, 128, 128, generator=g); ctx = torch.randn(4, 77, 64, generator=g)
+    t = torch.tensor([901, 601, 301, 1])
+    e1.prepare(hint, ctx)
+    a = e1.eps(x, t); n2 = e1.eps_launches()
+    assert e1.get_option('dec_lanes') == 2 and e1.get_option('gn_2k_min_hw') == 4096 and e1.get_option('xcd_auto_ratio') == 1
+    e1.set_option('dec_lanes', 0)
+    e1.prepare(hint, ctx)                                   # same arguments: re-plans because an option changed
+    b = e1.eps(x, t)
+    # no lanes: fewer launches; the full-batch decoder takes other tiles / split-K than the half-batch lanes: same values within the bf16 budget
+    assert e1.eps_launches() < n2 and float((b.float() - a.float()).norm() / a.float().norm()) < 1e-2
+    e1.set_option('gn_2k_min_hw', 64)                       # every GroupNorm with >= 64 pixels as two full-chip launches
+    e1.prepare(hint, ctx)
+    c = e1.eps(x, t)
+    assert float((c.float() - a.float()).norm() / a.float().norm()) < 2e-2      # (another plan of the same bf16 nets: measured 1.1e-2)
+    with pytest.raises(mlib.MkdError):
+        e1.set_option('no_such_option', 1)
+    lib = mlib.load()
+    assert lib.mkd_gemm_force_tile(3) == 0 and lib.mkd_gemm_force_tile(-1) == 0          # one context: the tuner may be driven
+    e2 = MkdEngine(NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
+                             hint_widths=(16, 16, 32, 32, 32, 32, 64)))
+    try:
+        assert e2.get_option('dec_lanes') == 2              # the other context's option did not leak
+        assert lib.mkd_gemm_force_tile(3) != 0 and b'live contexts' in lib.mkd_last_error()
+        assert lib.mkd_gemm_set_xcd_mode(1) != 0 and lib.mkd_gemm_set_override(64, 64, 64, 0, 1, 0, 1, 1) != 0
+        assert lib.mkd_gemm_force_tile(-1) == 0 and lib.mkd_gemm_set_xcd_mode(0) == 0    # restoring defaults is always allowed
+    finally:
+        e2.close()
+    assert lib.mkd_gemm_force_tile(3) == 0 and lib.mkd_gemm_force_tile(-1) == 0
+    e1.close()
