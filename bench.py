@@ -109,7 +109,18 @@ def live_pmc_passes(args):
     return out, 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py ' + ' '.join(work)
 
 
-def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None):
+def config_tag(args):
+    """Name of the workload in the committed profile files (tools/collect_profiles.sh TAG=...)."""
+    if args.interp:
+        return 'interp' if (args.batch == 4 and args.interp == 11 and args.res == 256) else None
+    if args.cfg:
+        return 'cfg' if (args.batch == 8 and args.res == 256) else None
+    if args.res == 512:
+        return 'r512' if args.batch == 8 else None
+    return 'b8_256' if (args.batch == 8 and args.res == 256) else None
+
+
+def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None, tag='b8_256'):
     """HBM-side bytes per launch of `kernel_fn`: FETCH_SIZE and WRITE_SIZE (KB -> bytes, FETCH doubled for wide streaming reads on gfx950,
     MI355X_MICROARCH.md §HBM).  `live` (live_pmc_passes): measured by this run on this box.  Otherwise from the COMMITTED rocprofv3
     summaries (profiles/), and the second return value says which files / commit they come from and whether the kernel sources are
@@ -123,9 +134,12 @@ def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None):
         if n:
             return b / n, {'collected_live': True, 'dispatches': n, 'command': live_note,
                            'formula': '2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the launches of the kernel function'}
-    for rnd in ('r3', 'r2'):
+    cands = [(f'r4_pmc_fetch_size_kb_{tag}.csv', f'r4_pmc_write_size_kb_{tag}.csv', f'r4_provenance_{tag}.json')] if tag else []
+    if tag == 'b8_256':
+        cands += [('r3_pmc_fetch_size_kb.csv', 'r3_pmc_write_size_kb.csv', 'r3_provenance.json')]
+    for f_fetch, f_write, f_prov in cands:
         tot = {}
-        for name, mult in ((f'{rnd}_pmc_fetch_size_kb.csv', 2.0), (f'{rnd}_pmc_write_size_kb.csv', 1.0)):
+        for name, mult in ((f_fetch, 2.0), (f_write, 1.0)):
             path = os.path.join(ROOT, 'profiles', name)
             if not os.path.exists(path):
                 tot = None
@@ -142,37 +156,48 @@ def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None):
         if tot is None:
             continue
         src = {'files': sorted('profiles/' + k for k in tot), 'collected_live': False, 'live_attempt': live_note}
-        prov = os.path.join(ROOT, 'profiles', f'{rnd}_provenance.json')
+        prov = os.path.join(ROOT, 'profiles', f_prov)
         if os.path.exists(prov):
             pv = json.load(open(prov))
             src.update(commit=pv.get('commit'), utc=pv.get('utc'), same_kernel_sources_as_this_run=pv.get('csrc_sha256_16') == _csrc_sha16())
         return sum(tot.values()), src
-    return None, None
+    return None, {'collected_live': False, 'files': None, 'live_attempt': live_note,
+                  'note': 'no committed rocprofv3 summaries for this workload (tools/collect_profiles.sh TAG=...): traffic not reported'}
 
 
-def l2_traffic_per_eval():
-    """L2 -> CU traffic of ONE eps evaluation at batch 8, 256x256, from the committed rocprofv3 summaries: per kernel, (TCC_HIT_sum +
-    TCC_MISS_sum) requests per launch (profiles/r3_pmc_l2_hit.csv, 128 B each) x its launches per evaluation (calls in
-    profiles/r3_kernel_stats_bench_b8_256.csv / the evaluations of that run: one per DDIM update kernel call + the 6
-    evaluation-equivalents of the roofline pass).  None when the summaries are absent."""
+def l2_traffic_per_eval(tag, attn_launches_per_eval):
+    """L2 -> CU traffic of ONE eps evaluation from the committed rocprofv3 summaries of this workload (tag): per kernel, (TCC_HIT_sum +
+    TCC_MISS_sum) requests per launch (profiles/r4_pmc_l2_hit_<tag>.csv, 128 B each) x its launches per evaluation.  The number of
+    evaluations inside the profiled run is DERIVED: calls of attention_kernel in the run / attention launches of one
+    evaluation in this run's plan - the profiled bench also runs eps_profile passes beside the loop.  None when the summaries are
+    absent."""
     import csv
+    if not tag or not attn_launches_per_eval:
+        return None
     try:
+        f_stats = os.path.join(ROOT, 'profiles', f'r4_kernel_stats_bench_{tag}.csv'); f_l2 = os.path.join(ROOT, 'profiles', f'r4_pmc_l2_hit_{tag}.csv')
         stats = {}
-        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r3_kernel_stats_bench_b8_256.csv'))):
+        for r in csv.DictReader(open(f_stats)):
             n = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
             stats[n] = stats.get(n, 0) + int(r['Calls'])
-        evals = stats.get('ddim_step_state_kernel', 0) + stats.get('ddim_step_kernel', 0) + 6          # (graph replay / eager loop)
-        if evals <= 6:
+        attn_calls = sum(v for k, v in stats.items() if k.startswith('attention_kernel'))
+        evals = attn_calls / float(attn_launches_per_eval)
+        if evals < 1:
             return None
         req = hit = 0.0
-        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r3_pmc_l2_hit.csv'))):
+        for r in csv.DictReader(open(f_l2)):
             k = r['kernel']
-            if k in ('merge_ff_out_kernel', 'pack_conv_weight_kernel', 'fold_layernorm_kernel') or not (k.split('<')[0] in stats or k in stats):
+            if k in ('merge_ff_out_kernel', 'pack_conv_weight_kernel', 'fold_layernorm_kernel', 'tfm_pack_units_kernel') or not (k.split('<')[0] in stats or k in stats):
                 continue                                    # (load-time kernels; torch's own kernels)
             per_eval = stats.get(k, 0) / evals
             req += (float(r['avg_TCC_HIT_sum']) + float(r['avg_TCC_MISS_sum'])) * per_eval
             hit += float(r['avg_TCC_HIT_sum']) * per_eval
-        return {'gb_per_eval': req * 128 / 1e9, 'hit_fraction': hit / req if req else None}
+        out = {'gb_per_eval': req * 128 / 1e9, 'hit_fraction': hit / req if req else None, 'evaluations_in_profiled_run': round(evals, 2),
+               'source': f'profiles/r4_pmc_l2_hit_{tag}.csv x profiles/r4_kernel_stats_bench_{tag}.csv'}
+        prov = os.path.join(ROOT, 'profiles', f'r4_provenance_{tag}.json')
+        if os.path.exists(prov):
+            out['same_kernel_sources_as_this_run'] = json.load(open(prov)).get('csrc_sha256_16') == _csrc_sha16()
+        return out
     except Exception:
         return None
 
@@ -377,7 +402,7 @@ def main():
         live, live_note = live_pmc_passes(args) if (args.live_pmc and world == 1) else (None, 'not attempted (--live-pmc 0 or more than one rank)')
         if live is None:
             log(f'live PMC: {live_note}; roofline.traffic from the committed summaries')
-        traffic, traffic_src = pmc_traffic_bytes_per_launch(dom, live, live_note)
+        traffic, traffic_src = pmc_traffic_bytes_per_launch(dom, live, live_note, config_tag(args))
         b2b_ms = sum(v['ms_b2b'] for k, v in prof.items() if fam[dom](k))
         roofline = {'bound': 'mfma', 'kernel': dom + ' (all tile configurations, one eps evaluation)', 'achieved': ach,
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
@@ -398,7 +423,7 @@ def main():
             hv = hb[hk]
             gbs = hv['bytes'] / (hv['ms'] * 1e-3) / 1e9
             gbs_b2b = hv['bytes'] / (hv['ms_b2b'] * 1e-3) / 1e9 if hv['ms_b2b'] > 0 else None
-            h_traffic, h_src = pmc_traffic_bytes_per_launch(tuple(hbm_fn[hk].split(' / ')), live, live_note)      # (every kernel function of the class)
+            h_traffic, h_src = pmc_traffic_bytes_per_launch(tuple(hbm_fn[hk].split(' / ')), live, live_note, config_tag(args))      # (every kernel function of the class)
             roofline_hbm = {'bound': 'hbm', 'kernel': f'{hbm_fn[hk]} ({hk} class, one eps evaluation)', 'achieved': gbs, 'peak': PEAK_HBM_GBS,
                             'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'traffic': h_traffic, 'traffic_source': h_src,
                             'launches_per_eval': hv['launches'], 'avg_launch_us': 1e3 * hv['ms'] / hv['launches'],
@@ -428,13 +453,14 @@ def main():
             'roofline_hbm': roofline_hbm,
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
-                     'launches_per_eval': eng.step_launches(), 'launches_per_standalone_eps': eng.eps_launches(),
+                     'launches_per_eval': eng.step_launches(use_graph=bool(args.graph), cfg=bool(args.cfg)) / (2 if args.cfg else 1), 'launches_per_step': eng.step_launches(use_graph=bool(args.graph), cfg=bool(args.cfg)),
+                     'launches_per_standalone_eps': eng.eps_launches(),
                      'device_gb': eng.device_bytes() / 1e9,
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),
                      'vae_decode_tflop_per_batch': eng.decode_flops() / 1e12 if args.decode else None,
                      # what the cache hierarchy moves per evaluation (committed PMC summaries of the default workload)
-                     'l2_traffic': (lambda t: None if (t is None or args.batch != 8 or args.res != 256 or args.cfg or args.interp) else
-                                    dict(t, tb_per_s_over_the_loop=t['gb_per_eval'] / (loop_ms / evals_per_step), source='profiles/r3_pmc_l2_hit.csv x profiles/r3_kernel_stats_bench_b8_256.csv'))(l2_traffic_per_eval())},
+                     'l2_traffic': (lambda t: None if t is None else dict(t, tb_per_s_over_the_loop=t['gb_per_eval'] / (loop_ms / evals_per_step)))(
+                         l2_traffic_per_eval(config_tag(args), prof.get('attention', {}).get('launches', 0)))},
             'kernel_classes_ms_per_eval': {k: round(v['ms'], 4) for k, v in prof.items() if v['ms'] > 0},
             # the same classes with their launches replayed back to back between one event pair (no per-launch event overhead)
             'kernel_classes_ms_per_eval_back_to_back': {k: round(v['ms_b2b'], 4) for k, v in prof.items() if v['ms_b2b'] > 0},

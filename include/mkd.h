@@ -57,6 +57,9 @@ typedef struct mkd_net_config {
 const char* mkd_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int mkd_abi_version(void);
+/* 1 when the library was built with 2-entry kernel argument tables (-DMKD_PAIR_N=2): the grouped encoder chain experiment
+ * (MKD_ENC_GROUP=1) is available; the default build has single-entry tables (1.9 % faster on the default plan) and refuses it. */
+int mkd_grouped_launches_available(void);
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* Replaces cldm.model.create_model(yaml) for the two nets (runs/test.py:27). */
@@ -87,9 +90,11 @@ int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
  *   "gn_slab_min_channels" slab-fed GroupNorm from this many channels (default 1280)
  *   "graph_steps"          DDIM steps per captured graph (default 5)
  * Unknown names return MKD_ERR_ARG.  The tile tuner's state (mkd_gemm_force_tile / _set_xcd_mode / _set_override) stays process-global
- * and is refused (MKD_ERR_STATE) for non-default values while more than one context is alive. */
+ * by design (single-kernel entries, tuners): a change makes EVERY live context re-plan at its next mkd_prepare; mkd_live_contexts()
+ * says how many there are. */
 int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value);
 int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value);
+int mkd_live_contexts(void);
 
 /* ---- conditioning ----------------------------------------------------------------------- */
 /* Binds the step-invariant conditioning for a batch (cond dict of makeup_diffuse.py:42-57,
@@ -180,7 +185,8 @@ double  mkd_eps_flops(const mkd_ctx* ctx);
 int     mkd_eps_launches(const mkd_ctx* ctx);
 /* Number of kernel launches of one DDIM step inside mkd_sample at the prepared shape (the time-embedding chain of mkd_eps is
  * computed once per call there, see mkd_sample; + the step setup and the x_{t-1} update). */
-int     mkd_step_launches(const mkd_ctx* ctx);
+int     mkd_step_launches(const mkd_ctx* ctx);                           /* graph replay, no guidance */
+int     mkd_step_launches_ex(const mkd_ctx* ctx, int use_graph, int cfg_on); /* as the loop is run: eager adds the timestep fill / table-row select, guidance the batch doubling */
 /* Kernel classes of the launch plan, and one mkd_eps with a hipEvent pair around every launch group:
  * per-class device milliseconds, executed FLOPs and launch counts (arrays of mkd_kind_count()). Synchronous.
  * csv_path (host string, may be NULL): also write one line per launch group (op,kind,label,ms,gflop). */

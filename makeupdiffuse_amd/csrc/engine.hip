@@ -673,7 +673,7 @@ struct mkd_ctx {
         if (gn_colstats_only && a.gn_stat) {
             GnOut g; g.gst = a.gn_stat; g.cg = a.gn_cg; g.coff = a.gn_coff; g.hw = a.gn_hw;
             a.gn_stat = nullptr;
-            op_gemm(a);
+            op_gemm(a, force_splitk);
             op_colstats((const bf16_t*)a.C, a.ldc, a.M / g.hw, g.hw, a.N, g);
             return;
         }
@@ -2331,6 +2331,7 @@ extern "C" {
 
 const char* mkd_last_error(void) { return g_last_error.c_str(); }
 int mkd_abi_version(void) { return 1; }
+int mkd_grouped_launches_available(void) { return MKD_PAIR_N > 1 ? 1 : 0; }
 
 int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
     if (!cfg || !out) return mkd_fail(MKD_ERR_ARG, "mkd_ctx_create: null argument");
@@ -2351,6 +2352,8 @@ int mkd_ctx_create(const mkd_net_config* cfg, mkd_ctx** out) {
         if (ss[0] && atoi(ss) == 0)
             return mkd_fail(MKD_ERR_UNSUPPORTED, "ROC_SYSTEM_SCOPE_SIGNAL=0 is not supported: the step graph's cross-queue join barriers wait on "
                                                  "completion signals that need system scope (a graph replay never completes); unset it");
+    if (MKD_PAIR_N < 2 && getenv("MKD_ENC_GROUP") && atoi(getenv("MKD_ENC_GROUP")) != 0)
+        return mkd_fail(MKD_ERR_UNSUPPORTED, "MKD_ENC_GROUP=1 needs a build with 2-entry argument tables (tools/build_variant.sh group -DMKD_PAIR_N=2)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mkd_fail(MKD_ERR_HIP, "no HIP device visible: libmkd has no CPU path");
@@ -2425,16 +2428,13 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
     return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
                        (hipStream_t)stream);
 }
-// The tile tuner's state (forced tile, XCD mode, per-shape overrides) is PROCESS-global: it belongs to the single-kernel entries and to
-// the tuners, which drive one context.  With more than one live context a non-default setting would silently re-plan all of them:
-// refused (per-context plan switches: mkd_ctx_set_option).
-static int tuner_guard(bool non_default, const char* what) {
-    if (non_default && g_live_contexts > 1)
-        return mkd_fail(MKD_ERR_STATE, std::string(what) + ": process-global tuner state with " + std::to_string(g_live_contexts) + " live contexts (use mkd_ctx_set_option)");
-    return 0;
-}
-int mkd_gemm_force_tile(int cfg) { int rc = tuner_guard(cfg >= 0, "mkd_gemm_force_tile"); if (rc) return rc; gemm_force_tile_cfg(cfg); return 0; }
-int mkd_gemm_set_xcd_mode(int mode) { int rc = tuner_guard(mode != 0, "mkd_gemm_set_xcd_mode"); if (rc) return rc; gemm_set_xcd_mode(mode); return 0; }
+// The tile tuner's state (forced tile, XCD mode, per-shape overrides) is PROCESS-global by design: it belongs to the single-kernel
+// entries and to the tuners.  A change bumps the global plan epoch, so EVERY live context re-plans at its next mkd_prepare and a plan
+// never runs with decisions of another setting (launch_gemm also checks planned slab counts).  Per-context plan switches:
+// mkd_ctx_set_option.  mkd_live_contexts() tells a tuner whether it is alone.
+int mkd_live_contexts(void) { return g_live_contexts; }
+int mkd_gemm_force_tile(int cfg) { gemm_force_tile_cfg(cfg); return 0; }
+int mkd_gemm_set_xcd_mode(int mode) { gemm_set_xcd_mode(mode); return 0; }
 int mkd_debug_poison(mkd_ctx* ctx) { return ctx ? ctx->debug_poison() : mkd_fail(MKD_ERR_ARG, "null ctx"); }
 int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value) {
     if (!ctx || !name) return mkd_fail(MKD_ERR_ARG, "mkd_ctx_set_option: null argument");
@@ -2467,7 +2467,6 @@ int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value) {
     return 0;
 }
 int mkd_gemm_set_override(int M, int N, int K, int conv3x3, int stride, int up, int cfg, int splitk) {
-    { int rc = tuner_guard(M > 0 && cfg >= 0, "mkd_gemm_set_override"); if (rc) return rc; }
     gemm_set_override(M, N, K, conv3x3, stride, up, cfg, splitk);
     return 0;
 }
@@ -2517,10 +2516,15 @@ int mkd_clip_encode(mkd_ctx* ctx, const int32_t* tokens, int batch, int n_tokens
 }
 double mkd_eps_flops(const mkd_ctx* ctx) { return ctx ? ctx->flops_eps : 0.0; }
 int mkd_eps_launches(const mkd_ctx* ctx) { return ctx ? ctx->launches_eps : 0; }
-int mkd_step_launches(const mkd_ctx* ctx) {
+// what sample_impl / build_segments enqueue per step: the evaluation (without its own time-embedding chain when the per-call table
+// is on) + graph replay: step setup (timestep, coefficients, table rows) and the state update; eager: timestep fill, table-row
+// select (table on) and the update; + the batch doubling of x with guidance
+int mkd_step_launches_ex(const mkd_ctx* ctx, int use_graph, int cfg_on) {
     if (!ctx) return 0;
-    return ctx->launches_eps - (ctx->temb_table ? ctx->launches_temb : 0) + 2;      // + step setup + DDIM update
+    const int eval = ctx->launches_eps - (ctx->temb_table ? ctx->launches_temb : 0);
+    return eval + (use_graph ? 2 : (ctx->temb_table ? 3 : 2)) + (cfg_on ? 1 : 0);
 }
+int mkd_step_launches(const mkd_ctx* ctx) { return mkd_step_launches_ex(ctx, 1, 0); }
 int64_t mkd_device_bytes(const mkd_ctx* ctx) { return ctx ? ctx->device_bytes() : 0; }
 
 // ---- single-kernel entry points ----------------------------------------------------------------------

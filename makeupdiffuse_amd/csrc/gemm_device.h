@@ -26,7 +26,7 @@ __device__ __forceinline__ void xcd_tile_order(int mode, int gz, int grp, int& b
 inline GemmArgs2 gemm_pack2(const GemmArgs& a, const GemmArgs* b, int gz) {
     GemmArgs2 r;
     r.g[0] = a; r.g[0].gz = gz;
-    r.g[1] = b ? *b : a; r.g[1].gz = gz;
+    if (MKD_PAIR_N > 1) { r.g[MKD_PAIR_N - 1] = b ? *b : a; r.g[MKD_PAIR_N - 1].gz = gz; }
     return r;
 }
 

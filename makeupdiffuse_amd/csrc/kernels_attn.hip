@@ -277,7 +277,7 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     if (Tq <= 0 || Tk <= 0 || batch <= 0 || heads <= 0) return mkd_fail(-1, "attention: empty problem");
     Pair<AttnIo> io;
     io.g[0] = AttnIo{q, k, v, o};
-    io.g[1] = second ? *second : io.g[0];
+    MKD_PAIR_SET2(io, second ? *second : io.g[0]);
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || dh % 8) return mkd_fail(-1, "attention: strides/dh must be multiples of 8");
     const float sl = scale * 1.4426950408889634f;
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile

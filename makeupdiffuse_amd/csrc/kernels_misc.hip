@@ -411,7 +411,7 @@ int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const
         const int threads = (Cout + 63) / 64 * 64;
         Pair<ConvInIo> io;
         io.g[0] = ConvInIo{w, bias, (bf16_t*)y, add};
-        io.g[1] = second ? *second : io.g[0];
+        MKD_PAIR_SET2(io, second ? *second : io.g[0]);
         hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, dim3((npix + ppb - 1) / ppb, second ? 2 : 1), dim3(threads), 0, stream, (const float*)x, io,
                            act, batch, Hin, Win, Cout, ppb);
         MKD_LAUNCH_CHECK("conv3x3_fewin_kernel");

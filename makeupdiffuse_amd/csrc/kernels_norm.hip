@@ -659,7 +659,7 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
     if (C % 8 || ld_in % 8 || ld_out % 8) return mkd_fail(-1, "groupnorm: C, ld must be multiples of 8");
     Pair<NormIo> io;
     io.g[0] = NormIo{x, y, gamma, beta};
-    io.g[1] = second ? *second : io.g[0];
+    MKD_PAIR_SET2(io, second ? *second : io.g[0]);
     if (groups > GN_MAX_GROUPS || groups <= 0 || C % groups) return mkd_fail(-1, "groupnorm: bad group count");
     if (!partials) return mkd_fail(-1, "groupnorm: partials workspace missing");
     // single-launch path: smallest group chunk whose channel span is a multiple of 8, slab small enough to
@@ -761,11 +761,11 @@ int launch_gn_from_slabs(const GemmArgs& a, const float* gamma, const float* bet
     Pair<NormIo> io;
     int rc = slab_args(a, batch, hw, ld_out, &sg.g[0]); if (rc) return rc;
     io.g[0] = NormIo{nullptr, y, gamma, beta};
-    sg.g[1] = sg.g[0]; io.g[1] = io.g[0];
+    MKD_PAIR_SET2(sg, sg.g[0]); MKD_PAIR_SET2(io, io.g[0]);
     if (a2) {
         if (a2->M != a.M || a2->N != a.N || a2->splitk != a.splitk || a2->ws == a.ws) return mkd_fail(-1, "gn_from_slabs: grouped problems must share the geometry and own their slabs");
-        rc = slab_args(*a2, batch, hw, ld_out, &sg.g[1]); if (rc) return rc;
-        io.g[1] = *second;
+        rc = slab_args(*a2, batch, hw, ld_out, &sg.g[MKD_PAIR_N - 1]); if (rc) return rc;
+        MKD_PAIR_SET2(io, *second);
     }
     const size_t lds = (size_t)(2 * (nt / 64) * gpb + 2 * gpb) * sizeof(float);
     dim3 grid(32 / gpb, batch, a2 ? 2 : 1);
@@ -823,7 +823,7 @@ int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, flo
     const int V = d / 8;
     Pair<NormIo> io;
     io.g[0] = NormIo{x, y, gamma, beta};
-    io.g[1] = second ? *second : io.g[0];
+    MKD_PAIR_SET2(io, second ? *second : io.g[0]);
     dim3 grid((rows + 3) / 4, second ? 2 : 1);
     if (V <= 64)       hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);
     else if (V <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, io, eps, rows, d, ldx);

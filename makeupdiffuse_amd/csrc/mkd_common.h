@@ -101,7 +101,15 @@ struct GemmArgs {
 // the pair costs ONE dependent dispatch instead of two on two contending queues.  Same kernels, same tiles, same order of
 // operations per output: results are bit-identical to two separate launches.
 // ---------------------------------------------------------------------------------------------
-template <typename T> struct Pair { T g[2]; };
+// MKD_PAIR_N = 1 (default build since round 4): single-entry argument tables.  The 2-entry form on every launch cost the DEFAULT
+// two-chain plan 1.9 % (doubled kernarg blocks, a blockIdx.z-indexed indirection in every kernel: profiles/exp_r4_pair_form.txt,
+// 5.39 vs 5.29 ms per evaluation, three alternating rounds), and its only user, the grouped encoder chain
+// (MKD_ENC_GROUP, 10 % slower than two chains), is an experiment: build it with tools/build_variant.sh group -DMKD_PAIR_N=2.
+#ifndef MKD_PAIR_N
+#define MKD_PAIR_N 1
+#endif
+template <typename T> struct Pair { T g[MKD_PAIR_N]; };
+#define MKD_PAIR_SET2(tab, val) do { if (MKD_PAIR_N > 1) (tab).g[MKD_PAIR_N - 1] = (val); } while (0)
 typedef Pair<GemmArgs> GemmArgs2;
 struct NormIo { const bf16_t* x; bf16_t* y; const float* gamma; const float* beta; };     // GroupNorm / LayerNorm operands of one problem
 struct AttnIo { const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; };

@@ -83,8 +83,14 @@ def gather_shards(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor
         if local.shape[0] != n_total:
             raise ValueError('single-process gather: shard is not the whole batch')
         return local
-    world = dist.get_world_size(group)          # (a group of one still runs the collective: same code path as N ranks)
+    world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if world == 1 and not os.environ.get('MKD_DIST_BACKEND'):
+        # a group of one that the CALLER initialised (e.g. torchrun --nproc-per-node 1): nothing to exchange, same storage back.
+        # Only a group of one that was asked for explicitly (MKD_DIST_BACKEND: the RCCL-of-one rehearsal) runs the collective.
+        if local.shape[0] != n_total:
+            raise ValueError('world of one: shard is not the whole batch')
+        return local
     lo, hi = shard_range(n_total, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError(f'rank {rank}: shard has {local.shape[0]} samples, expected {hi - lo}')

@@ -432,9 +432,9 @@ class MkdEngine:
     def eps_launches(self) -> int:
         return int(self.lib.mkd_eps_launches(self._ctx))
 
-    def step_launches(self) -> int:
-        """Kernel launches of one DDIM step inside ``sample`` (time embedding hoisted out of the loop)."""
-        return int(self.lib.mkd_step_launches(self._ctx))
+    def step_launches(self, use_graph: bool = True, cfg: bool = False) -> int:
+        """Kernel launches of one DDIM step inside ``sample`` (time embedding hoisted out of the loop), as that loop is run."""
+        return int(self.lib.mkd_step_launches_ex(self._ctx, int(use_graph), int(cfg)))
 
     def device_bytes(self) -> int:
         return int(self.lib.mkd_device_bytes(self._ctx))

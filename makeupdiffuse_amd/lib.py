@@ -45,6 +45,7 @@ _L = C.c_int64
 SIGNATURES = {
     'mkd_last_error': (C.c_char_p, []),
     'mkd_abi_version': (_I, []),
+    'mkd_grouped_launches_available': (_I, []),
     'mkd_ctx_create': (_I, [C.POINTER(NetConfigC), C.POINTER(_P)]),
     'mkd_ctx_destroy': (None, [_P]),
     'mkd_load_weight': (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L)]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     'mkd_ctx_set_option': (_I, [_P, C.c_char_p, C.c_double]),
     'mkd_ctx_get_option': (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     'mkd_debug_tfm_trace': (_I, [_P]),
+    'mkd_live_contexts': (_I, []),
     'mkd_prepare': (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_prepare_interp': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_eps': (_I, [_P, _P, _P, _P, _P]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     'mkd_eps_flops': (C.c_double, [_P]),
     'mkd_eps_launches': (_I, [_P]),
     'mkd_step_launches': (_I, [_P]),
+    'mkd_step_launches_ex': (_I, [_P, _I, _I]),
     'mkd_device_bytes': (_L, [_P]),
     'mkd_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -12,6 +12,19 @@ from makeupdiffuse_amd.engine import MkdEngine, NetConfig
 from oracle import nets, sampler
 
 pytestmark = pytest.mark.gpu
+
+
+def _grouped():
+    from makeupdiffuse_amd import lib as _mlib
+    try:
+        return bool(_mlib.load().mkd_grouped_launches_available())
+    except Exception:
+        return False
+
+
+GROUPED = _grouped()
+NEED_GROUP = ('grouped (2-problem) launches are an experiment build since round 4: tools/build_variant.sh group -DMKD_PAIR_N=2, '
+              'MKD_LIB_PATH=makeupdiffuse_amd/libmkd_group.so (the default build has single-entry argument tables: +1.9 %)')
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 SMALL = dict(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
              hint_widths=(16, 16, 32, 32, 32, 32, 64))
@@ -270,6 +283,8 @@ def test_stream_lanes_are_race_free_and_match_golden(dec_lanes, enc_lanes, overl
     evaluation produces, evaluate, and require the golden result, bit-identical
     across repetitions - a kernel that runs ahead of its producer would read NaN instead of the previous call's values."""
     monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes)); monkeypatch.setenv('MKD_ENC_LANES', str(enc_lanes))
+    if group and not GROUPED:
+        pytest.skip(NEED_GROUP)
     monkeypatch.setenv('MKD_DEC_OVERLAP', str(overlap)); monkeypatch.setenv('MKD_LANE_HELPERS', str(helpers))
     monkeypatch.setenv('MKD_ENC_GROUP', str(group))
     g = np.load(os.path.join(GOLD, 'small_eps.npz'))
@@ -401,6 +416,8 @@ def test_grouped_encoder_equals_the_two_chain_plan_bit_for_bit(dec_lanes, monkey
     two streams (reference diffmk/makeup_diffuse.py:164-168, the two net calls of apply_model).  Same kernels, same tiles, same
     order of operations per output element: the eps of a ragged batch, the 5-step latent (eager and graph replay) and the guided
     loop are equal BIT FOR BIT, after NaN-poisoning; the grouped plan has one launch per encoder op pair."""
+    if not GROUPED:
+        pytest.skip(NEED_GROUP)
     monkeypatch.setenv('MKD_DEC_LANES', str(dec_lanes))
     res = {}
     for group in (0, 1):
@@ -527,9 +544,10 @@ def test_xcd_auto_order_changes_no_bit(monkeypatch):
         assert torch.equal(res[r][0], res['2'][0]) and torch.equal(res[r][1], res['2'][1]), f'MKD_XCD_AUTO_RATIO={r} changed the result'
 
 
-def test_plan_options_are_per_context_and_the_global_tuner_is_guarded():
+def test_plan_options_are_per_context():
     """plan switches live in the context (mkd_ctx_set_option: the next prepare re-plans, another context is not
-    touched); the tile tuner's process-global state is refused for non-default values while two contexts are alive."""
+    touched).  The tile tuner's state stays process-global by design (include/mkd.h): a change re-plans every live context
+    (test_split_setting_changed_after_prepare_is_loud_then_replanned)."""
     import ctypes as C
     from makeupdiffuse_amd import lib as mlib
     e1 = MkdEngine(NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
@@ -553,15 +571,13 @@ def test_plan_options_are_per_context_and_the_global_tuner_is_guarded():
     with pytest.raises(mlib.MkdError):
         e1.set_option('no_such_option', 1)
     lib = mlib.load()
-    assert lib.mkd_gemm_force_tile(3) == 0 and lib.mkd_gemm_force_tile(-1) == 0          # one context: the tuner may be driven
+    n_live = lib.mkd_live_contexts()
     e2 = MkdEngine(NetConfig(model_channels=64, channel_mult=(1, 2), attention_resolutions=(1, 2), num_heads=2, context_dim=64,
                              hint_widths=(16, 16, 32, 32, 32, 32, 64)))
     try:
+        assert lib.mkd_live_contexts() == n_live + 1
         assert e2.get_option('dec_lanes') == 2              # the other context's option did not leak
-        assert lib.mkd_gemm_force_tile(3) != 0 and b'live contexts' in lib.mkd_last_error()
-        assert lib.mkd_gemm_set_xcd_mode(1) != 0 and lib.mkd_gemm_set_override(64, 64, 64, 0, 1, 0, 1, 1) != 0
-        assert lib.mkd_gemm_force_tile(-1) == 0 and lib.mkd_gemm_set_xcd_mode(0) == 0    # restoring defaults is always allowed
     finally:
         e2.close()
-    assert lib.mkd_gemm_force_tile(3) == 0 and lib.mkd_gemm_force_tile(-1) == 0
+    assert lib.mkd_live_contexts() == n_live
     e1.close()
