@@ -22,7 +22,7 @@ BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph 0 $EXTRA"
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python3 $BENCH > $OUT/${R}_rocprof_run_${TAG}.log 2>&1
 F=$(find /tmp/prof_stats -name 'p_kernel_stats.csv' | head -1); cp "$F" $OUT/${R}_kernel_stats_bench_${TAG}.csv
-tail -1 $OUT/${R}_rocprof_run_${TAG}.log > $OUT/${R}_bench_line_under_profiler_${TAG}.json
+grep "^{" $OUT/${R}_rocprof_run_${TAG}.log | tail -1 > $OUT/${R}_bench_line_under_profiler_${TAG}.json || true
 pmc() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/prof_$name
