@@ -292,6 +292,7 @@ int  mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, 
 void mkd_tfm_tail_destroy(mkd_tfm_tail* h);
 /* Experiment builds (-DMKD_TFM_TRACE) only: device buffer [workgroups][8][32] of int64 time stamps; a no-op in the product build. */
 int  mkd_debug_tfm_trace(long long* buf);
+int  mkd_debug_attn_trace(long long* buf);      /* -DMKD_ATTN_TRACE builds: [workgroup][wave][8] cycle sums per phase of attention_kernel */
 int  mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream);
 int  mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_t* h0, int ldh, const uint16_t* xin, int ldx,
                       uint16_t* out, int ldo, int M, int T, void* stream);

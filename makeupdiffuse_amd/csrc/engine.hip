@@ -2734,6 +2734,7 @@ int mkd_tfm_tail_create(int d, const float* to_out1_w, const float* to_out1_b, c
 }
 /* experiment builds (-DMKD_TFM_TRACE) only: device buffer [workgroups][8][32] of int64 time stamps; a no-op in the product build */
 int mkd_debug_tfm_trace(long long* buf) { tfm_tail_set_trace(buf); return 0; }
+int mkd_debug_attn_trace(long long* buf) { return attn_set_trace(buf); }
 int mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream) {
     if (!h) return mkd_fail(MKD_ERR_ARG, "null handle");
     if (batch > h->kv_batch) {

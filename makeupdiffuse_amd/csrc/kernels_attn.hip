@@ -27,7 +27,7 @@ namespace {
 #define MKD_ATTN_TAIL 1
 #endif
 
-template <int DH, int KT, int MSUM = 0>
+template <int DH, int KT, int MSUM = 0, int NWV = 4>
 struct AttnCfg {
     static constexpr int TAIL = ((MKD_ATTN_TAIL == 2 || (MKD_ATTN_TAIL == 1 && KT == 96)) && (DH % 32)) ? 1 : 0;   // one 16-deep step (v_mfma_f32_16x16x16_bf16) for dh = 8, 16, 40, 80
     static constexpr int KS = TAIL ? DH / 32 : (DH + 31) / 32;          // 32-deep k-steps of QK^T
@@ -42,6 +42,19 @@ struct AttnCfg {
     // 4096 keys: 445 -> 427 us).  Also tried in round 4 and dropped: two K/V tile buffers with ONE barrier per tile (+7 % at dh 40,
     // equal at dh 80).
     static constexpr int ONES = (MSUM && DVP > DH) ? 1 : 0;
+    // MSUM == 2, additionally (needs a spare column in the padded K tile too, dh 40 -> 64): the softmax's  s c - m  on the matrix cores.
+    // Q is pre-scaled by c = scale log2(e), column DH of the K tile holds 1.0 and element DH of the query's Q fragment holds -m', the
+    // row's REFERENCE (a bf16 value, so that it can live in the fragment): the MFMAs deliver s c - m' and the vector ALUs only take
+    // exp2 and a max per score.  The reference is updated lazily (cdna_hip_programming.md T13): only when some score of the tile
+    // exceeds it by more than OFFS_THRESH (p <= 2^OFFS_THRESH is harmless in bf16 / fp32), or on the first tile; then the tile's scores
+    // are corrected, O (with its denominator row) rescaled and the Q element rewritten.  Any reference gives the same softmax as long as
+    // numerator, denominator and rescale use the same one.
+    static constexpr int OFFS = (MSUM == 2 && ONES && KS * 32 > DH && !TAIL) ? 1 : 0;
+    static constexpr float OFFS_THRESH = 6.0f;
+    // ASYNC: unconditional tile loads, padding applied at the LDS store (see the kernel).  Measured per shape on one box (round 4, us,
+    // conditional / unconditional): 4096^2 dh 40 419 / 387, 1024^2 dh 40 32.8 / 29.4, 256^2 dh 80 11.1 / 9.8 - but 1024^2 dh 80 46.0 / 47.7
+    // (one more live 128-bit register per thread: a wave of occupancy), 256^2 dh 160 14.0 / 14.7, one-tile cross-attention +1-2 %.
+    static constexpr int ASYNC = (KT == 64 && (DH < 80 || (DH == 80 && NWV == 4))) ? 1 : 0;
     static constexpr int KROW = DHP * 2 + 16;            // K tile row stride in bytes (pad: bank spread)
     // V tile stays ROW-MAJOR [key][d] and is read transposed by ds_read_b64_tr_b16 (gfx950).  A 32-lane half reads 8
     // consecutive key rows x 4 column quads: conflict-free when the row stride in dwords is 8 * odd.
@@ -52,6 +65,12 @@ struct AttnCfg {
     static_assert(DH % 8 == 0 && (!TAIL || DH % 32 <= 16), "head dim: multiple of 8 (tail of at most 16 past the 32-deep steps)");
 };
 
+#ifdef MKD_ATTN_TRACE
+__device__ long long* g_attn_trace_dev = nullptr;      // experiment builds: [workgroup][wave][8] cycle sums per phase (tools/exp_r4_attn_trace.py)
+#define ATT_T(i) do { const long long now_ = clock64(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define ATT_T(i) do { } while (0)
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
     // grouped launch: grid z selects the problem (same geometry, own tensors)
     const bf16_t* __restrict__ const Q = io.g[blockIdx.z].q; const bf16_t* __restrict__ const K = io.g[blockIdx.z].k;
     const bf16_t* __restrict__ const V = io.g[blockIdx.z].v; bf16_t* __restrict__ const O = io.g[blockIdx.z].o;
-    using C = AttnCfg<DH, KT, MSUM>;
+    using C = AttnCfg<DH, KT, MSUM, NW>;
     static_assert(KT % 32 == 0, "key tile: whole 32-key PV steps");
     constexpr int KB = KT / 16;          // 16-key blocks of S^T
     extern __shared__ __attribute__((aligned(16))) char smem[];        // C::KBYTES + C::VBYTES (66 KB for dh 160 with 96-key tiles)
@@ -99,10 +118,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         }
     }
 
+    if (C::OFFS) {          // pre-scaled queries: the MFMA delivers scores in the log2 domain
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)((float)qf[s][j] * scale_log2e);
+    }
     f32x4 oacc[C::MD];
 #pragma unroll
     for (int i = 0; i < C::MD; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = 0.f;        // OFFS: the row's reference, held as -m_ref in element DH of the Q fragment (0 until the first tile sets it)
 
     const bf16_t* kbase = K + (size_t)b * Tk * ldk + h * DH;
     const bf16_t* vbase = V + (size_t)b * Tk * ldv + h * DH;
@@ -113,50 +139,87 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
     constexpr int NT = 64 * NW;
     constexpr int KCHUNKS = KT * (C::DHP / 8), VCHUNKS = KT * (C::DVP / 8);
     constexpr int KPT = (KCHUNKS + NT - 1) / NT, VPT = (VCHUNKS + NT - 1) / NT;
-    U16x8 kreg[KPT], vreg[VPT];
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v kreg[KPT], vreg[VPT];          // (opaque 128-bit values until they are stored: nothing to unpack, nothing for the compiler to hoist)
+    // The tile's global loads are UNCONDITIONAL (out-of-range chunks read the head's first row instead): a load under a divergent
+    // branch makes the compiler wait for it at the join (s_waitcnt vmcnt(0) right behind the "prefetch": a full L2 / HBM round trip
+    // exposed per key tile - 1425 of 4150 cycles per wave and tile in the phase trace, profiles/exp_r4_attn_trace.txt).  Zero padding,
+    // the ones column (ONES) and the reference column (OFFS) are applied when the registers are stored to LDS.
     auto prefetch = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
-            U16x8 d;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d.v[j] = 0;
-            if (idx < KCHUNKS && key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(kbase + (size_t)(key0 + r) * ldk + c * 8);
-            kreg[i] = d;
+            const bool ok = idx < KCHUNKS && key0 + r < Tk && c * 8 < DH;
+            const size_t off = ok ? (size_t)(key0 + r) * ldk + c * 8 : 0;
+            if (C::ASYNC) kreg[i] = *(const u32x4v*)(kbase + off);
+            else { const u32x4v z = {0u, 0u, 0u, 0u}; kreg[i] = z; if (ok) kreg[i] = *(const u32x4v*)(kbase + off); }
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
-            U16x8 d;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d.v[j] = 0;
-            if (idx < VCHUNKS && key0 + r < Tk && c * 8 < DH) d = *(const U16x8*)(vbase + (size_t)(key0 + r) * ldv + c * 8);
-            if (C::ONES && idx < VCHUNKS && key0 + r < Tk && c * 8 == DH) d.v[0] = 0x3F80;       // bf16 1.0 in column DH
-            vreg[i] = d;
+            const bool ok = idx < VCHUNKS && key0 + r < Tk && c * 8 < DH;
+            const size_t off = ok ? (size_t)(key0 + r) * ldv + c * 8 : 0;
+            if (C::ASYNC) vreg[i] = *(const u32x4v*)(vbase + off);
+            else { const u32x4v z = {0u, 0u, 0u, 0u}; vreg[i] = z; if (ok) vreg[i] = *(const u32x4v*)(vbase + off); }
         }
     };
+    // the chunk as it goes to LDS: zero outside the tensor; 1.0 in column DH of valid keys where the kernel uses that column
+    auto kfix = [&](int i, int key0) {
+        const int idx = tid + i * NT;
+        const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
+        u32x4v d = kreg[i];
+        if (C::ASYNC) {
+            asm volatile("" : "+v"(d));           // the value is looked at HERE, one tile after its load was issued
+            const bool ok = key0 + r < Tk && c * 8 < DH;
+            const u32x4v z = {0u, 0u, 0u, 0u};
+            d = ok ? d : z;
+        }
+        if (C::OFFS && key0 + r < Tk && c * 8 == DH) d.x = 0x3F80u;       // bf16 1.0 in column DH (the rest of the chunk is padding): adds the query's -m_ref
+        return d;
+    };
+    auto vfix = [&](int i, int key0) {
+        const int idx = tid + i * NT;
+        const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
+        u32x4v d = vreg[i];
+        if (C::ASYNC) {
+            asm volatile("" : "+v"(d));
+            const bool ok = key0 + r < Tk && c * 8 < DH;
+            const u32x4v z = {0u, 0u, 0u, 0u};
+            d = ok ? d : z;
+        }
+        if (C::ONES && key0 + r < Tk && c * 8 == DH) d.x = 0x3F80u;       // bf16 1.0 in column DH
+        return d;
+    };
     prefetch(0);
+#ifdef MKD_ATTN_TRACE
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+#endif
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
+        ATT_T(6);
         __syncthreads();                                   // previous tile fully consumed
+        ATT_T(0);
         // ---- registers -> LDS: K tile [64][DHP] and V tile [64][DVP], both row-major and zero padded ----
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
-            if (idx < KCHUNKS) *(U16x8*)(ks + r * C::KROW + c * 16) = kreg[i];
+            if (idx < KCHUNKS) *(u32x4v*)(ks + r * C::KROW + c * 16) = kfix(i, key0);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
-            if (idx < VCHUNKS) *(U16x8*)(vs + r * C::VROW + c * 16) = vreg[i];
+            if (idx < VCHUNKS) *(u32x4v*)(vs + r * C::VROW + c * 16) = vfix(i, key0);
         }
+        ATT_T(1);
         __syncthreads();
+        ATT_T(2);
         if (t + 1 < ntiles) prefetch(key0 + KT);           // in flight while this tile is consumed
+        ATT_T(3);
 
         // ---- S^T[key][q] for KB key blocks of 16 ------------------------------------------------
         f32x4 st[KB];
@@ -186,44 +249,91 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         // scale folded into one FMA per score: p = exp2(s*c - m), m = running max of s*c (c = scale*log2(e) > 0).
         // VALU, not MFMA, bounds this kernel (16 scores per lane per tile), so every per-score op counts: masking only
         // on a partial / causal tile, raw v_exp_f32, O rescaled only when some row's max moved.
-        float mx = -INFINITY;
-        if (causal || key0 + KT > Tk) {
+#ifdef MKD_ATTN_TRACE
+        asm volatile("" :: "v"(st[0]), "v"(st[KB - 1]));
+#endif
+        ATT_T(4);
+        if (C::OFFS) {
+            // st = s c - m_ref already.  Mask a partial last tile, take the tile's maximum (only to detect a reference that has
+            // fallen too far behind), exponentiate.
+            float mx = -INFINITY;
+            if (key0 + KT > Tk) {
 #pragma unroll
-            for (int mf = 0; mf < KB; ++mf)
+                for (int mf = 0; mf < KB; ++mf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + 16 * mf + 4 * g + r;
-                    const float s = key < key_lim ? st[mf][r] : -INFINITY;
-                    st[mf][r] = s;
-                    mx = fmaxf(mx, s);
-                }
-        } else {
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = (key0 + 16 * mf + 4 * g + r < Tk) ? st[mf][r] : -INFINITY;
+                        st[mf][r] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+            } else {
 #pragma unroll
-            for (int mf = 0; mf < KB; ++mf)
+                for (int mf = 0; mf < KB; ++mf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * scale_log2e);   // finite: the first tile always holds a visible key
-        float psum = 0.f;
-#pragma unroll
-        for (int mf = 0; mf < KB; ++mf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mf][r], scale_log2e, -m_new));
-                st[mf][r] = pv;
-                if (!C::ONES) psum += pv;
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
             }
-        if (__any(m_new != m_run)) {                           // wave-uniform: after the first tiles the max rarely moves
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const bool need = t == 0 || mx > C::OFFS_THRESH;
+            if (__any(need)) {                                     // wave-uniform; rare after the first tiles
+                const float m_new = need ? (float)(__bf16)(m_ref + mx) : m_ref;          // the new reference must be a bf16 value
+                const float delta = m_new - m_ref;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref = m_new;
 #pragma unroll
-            for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
-        }
-        l_run += psum;
+                for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[mf][r] -= delta;
+#pragma unroll
+                for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
+                if (g == (DH % 32) / 8) qf[DH / 32][DH % 8] = (__bf16)(-m_ref);
+            }
+#pragma unroll
+            for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[mf][r] = __builtin_amdgcn_exp2f(st[mf][r]);
+        } else {
+            float mx = -INFINITY;
+            if (causal || key0 + KT > Tk) {
+    #pragma unroll
+                for (int mf = 0; mf < KB; ++mf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + 16 * mf + 4 * g + r;
+                        const float s = key < key_lim ? st[mf][r] : -INFINITY;
+                        st[mf][r] = s;
+                        mx = fmaxf(mx, s);
+                    }
+            } else {
+    #pragma unroll
+                for (int mf = 0; mf < KB; ++mf)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * scale_log2e);   // finite: the first tile always holds a visible key
+            float psum = 0.f;
+    #pragma unroll
+            for (int mf = 0; mf < KB; ++mf)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[mf][r], scale_log2e, -m_new));
+                    st[mf][r] = pv;
+                    if (!C::ONES) psum += pv;
+                }
+            if (__any(m_new != m_run)) {                           // wave-uniform: after the first tiles the max rarely moves
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+    #pragma unroll
+                for (int i = 0; i < C::MD; ++i) oacc[i] *= alpha;
+            }
+            l_run += psum;
 
+        }
+
+        ATT_T(5);
         // ---- O^T[d][q] += V^T[d][key'] P^T[key'][q]; key'(g, j) = 32*s + (j<4 ? 4g+j : 16+4g+j-4) -----
 #pragma unroll
         for (int s = 0; s < KT / 32; ++s) {
@@ -247,6 +357,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         }
     }
 
+#ifdef MKD_ATTN_TRACE
+    ATT_T(6);
+    if (g_attn_trace_dev && lane == 0) {
+        long long* o_ = g_attn_trace_dev + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + w) * 8;
+        for (int i = 0; i < 8; ++i) o_[i] = tacc[i];
+    }
+#endif
     if (C::ONES) {
         l_run = __shfl(oacc[DH / 16][DH % 4], 16 * ((DH % 16) / 4) + qc, 64);      // row DH of O^T: lane group (DH % 16) / 4, register DH % 4
     } else {
@@ -271,6 +388,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
 
 }  // namespace
 
+int attn_set_trace(long long* buf) {
+#ifdef MKD_ATTN_TRACE
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace_dev), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : -2;
+#else
+    (void)buf; return 0;
+#endif
+}
+
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
                      hipStream_t stream, int causal, const AttnIo* second) {
@@ -283,10 +409,18 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
     static const bool kt96 = !(getenv("MKD_ATTN_KT96") && atoi(getenv("MKD_ATTN_KT96")) == 0);      // (A/B knob)
     const bool one96 = kt96 && !wide && !causal && Tk > 64 && Tk <= 96;      // cross-attention (77 context keys): one 96-key tile
-#ifndef MKD_ATTN_MSUM_MIN
-#define MKD_ATTN_MSUM_MIN 2048
+#ifndef MKD_ATTN_OFFS_MIN
+#define MKD_ATTN_OFFS_MIN 1024
 #endif
-    const bool msum = wide && Tk >= MKD_ATTN_MSUM_MIN && !causal;         // softmax denominators on the matrix cores (AttnCfg::ONES) where it measured faster
+    // softmax work moved onto the matrix cores in the long self-attention (AttnCfg::ONES / OFFS): 2 = reference subtraction and
+    // denominators (head dims with spare K and V columns in their padded tiles: 40), 1 = denominators only, from 2048 keys
+    int msum = (wide && !causal) ? ((Tk >= MKD_ATTN_OFFS_MIN && dh == 40) ? 2 : (Tk >= 2048 ? 1 : 0)) : 0;
+#ifdef MKD_ATTN_TRACE
+    if (const char* fm = getenv("MKD_ATTN_MODE")) msum = (wide && !causal) ? atoi(fm) : 0;      // (experiment builds only)
+#endif
+#ifdef MKD_ATTN_FORCE_MODE
+    msum = (wide && !causal) ? MKD_ATTN_FORCE_MODE : 0;
+#endif
     const int qb = wide ? 128 : 64;
     dim3 grid((Tq + qb - 1) / qb, batch * heads, second ? 2 : 1);
 #define MKD_ATTN_LAUNCH(D, NWV, KTV, MS)                                                                      \
@@ -303,7 +437,8 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     } while (0)
 #define MKD_ATTN_CASE(D)                                                                                      \
     case D:                                                                                                   \
-        if (wide && msum) MKD_ATTN_LAUNCH(D, 8, 64, 1);                                                       \
+        if (wide && msum == 2) MKD_ATTN_LAUNCH(D, 8, 64, 2);                                                  \
+        else if (wide && msum) MKD_ATTN_LAUNCH(D, 8, 64, 1);                                                  \
         else if (wide) MKD_ATTN_LAUNCH(D, 8, 64, 0);                                                          \
         else if (one96) MKD_ATTN_LAUNCH(D, 4, 96, 0);                                                         \
         else MKD_ATTN_LAUNCH(D, 4, 64, 0);                                                                    \

@@ -195,6 +195,7 @@ int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1
 int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                      bf16_t* o, int ldo, int batch, int Tq, int Tk, int heads, int dh, float scale,
                      hipStream_t stream, int causal = 0, const AttnIo* second = nullptr);
+int attn_set_trace(long long* buf);      // -DMKD_ATTN_TRACE builds: per-phase cycle sums of the attention kernel
 int launch_geglu(const bf16_t* x, bf16_t* y, int rows, int inner, hipStream_t stream);
 int launch_conv3x3_direct(const void* x, int in_nchw_f32, const bf16_t* w, const float* bias, void* y,
                           int out_nchw_f32, int act, const bf16_t* add, int batch, int Hin, int Win,

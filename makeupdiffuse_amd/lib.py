@@ -57,6 +57,7 @@ SIGNATURES = {
     'mkd_ctx_set_option': (_I, [_P, C.c_char_p, C.c_double]),
     'mkd_ctx_get_option': (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     'mkd_debug_tfm_trace': (_I, [_P]),
+    'mkd_debug_attn_trace': (_I, [_P]),
     'mkd_live_contexts': (_I, []),
     'mkd_prepare': (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_F), _I, _P]),
     'mkd_prepare_interp': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, C.POINTER(_F), _I, _P]),
