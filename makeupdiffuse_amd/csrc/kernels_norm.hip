@@ -153,8 +153,11 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const P
         if (NV > 0) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
+                // UNCONDITIONAL loads (rows past the slab re-read its last row and are ignored below): under `if (r < hw)` the
+                // compiler waits for every load at the branch join - s_waitcnt vmcnt(0) behind each of the NV loads, NV serial
+                // round trips instead of one (round 4: found in the ISA; the "5.1 of 10.9 us waiting for loads" of DESIGN 4.5)
                 const int r = pl + i * P;
-                if (r < hw) keep[i] = *(const U16x8*)(xin + (size_t)r * ld_in);
+                keep[i] = *(const U16x8*)(xin + (size_t)(r < hw ? r : hw - 1) * ld_in);
             }
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -569,25 +572,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const Pair<NormIo> io, f
     float f[NV][8];
     f32x4 pg[NV][2], pb[NV][2];               // gamma / beta: issued together with the row, consumed after the statistics
     float s = 0.f;
+    // every load UNCONDITIONAL (vectors past the row re-read vector 0 and are zeroed / ignored below): a load under a per-lane
+    // condition is waited for at the branch join - one serial round trip per vector (round 4)
+    U16x8 tv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = lane + 64 * i;
-        if (v < V) {
-            pg[i][0] = *(const f32x4*)(gamma + v * 8); pg[i][1] = *(const f32x4*)(gamma + v * 8 + 4);
-            pb[i][0] = *(const f32x4*)(beta + v * 8); pb[i][1] = *(const f32x4*)(beta + v * 8 + 4);
-        }
+        const int v = lane + 64 * i, vc = v < V ? v : 0;
+        tv[i] = *(const U16x8*)(x + (size_t)row * ldx + vc * 8);
+        pg[i][0] = *(const f32x4*)(gamma + vc * 8); pg[i][1] = *(const f32x4*)(gamma + vc * 8 + 4);
+        pb[i][0] = *(const f32x4*)(beta + vc * 8); pb[i][1] = *(const f32x4*)(beta + vc * 8 + 4);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = lane + 64 * i;
-        if (v < V) {
-            const U16x8 t = *(const U16x8*)(x + (size_t)row * ldx + v * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { f[i][j] = bf16_to_f32(t.v[j]); s += f[i][j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
-        }
+        for (int j = 0; j < 8; ++j) { f[i][j] = v < V ? bf16_to_f32(tv[i].v[j]) : 0.f; s += f[i][j]; }
     }
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
