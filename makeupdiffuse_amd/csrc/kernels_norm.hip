@@ -185,14 +185,18 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const P
             }
         }
     }
-    // gamma / beta of this thread's 8 channels: fetched now, next to the slab loads, not after the statistics barriers
+    // gamma / beta of this thread's 8 channels: fetched now, next to the slab loads, not after the statistics barriers - except in the
+    // 1024-thread instantiation (64 registers per thread: with its 8 slab vectors in flight at once they would spill), which fetches
+    // them behind the statistics
+    constexpr bool AFFINE_EARLY = NV != 8;
     float pg[8], pb[8];
-    if (active) {
+    auto load_affine = [&]() {
         const f32x4 g0 = *(const f32x4*)(gamma + c0 + v * 8), g1 = *(const f32x4*)(gamma + c0 + v * 8 + 4);
         const f32x4 b0 = *(const f32x4*)(beta + c0 + v * 8), b1 = *(const f32x4*)(beta + c0 + v * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pg[j] = g0[j]; pg[4 + j] = g1[j]; pb[j] = b0[j]; pb[4 + j] = b1[j]; }
-    }
+    };
+    if (AFFINE_EARLY && active) load_affine();
     float* ssum = s_red;                      // [NT][8]
     float* ssq = s_red + NT * 8;              // [NT][8]
     float* csum = s_red + 2 * NT * 8;         // [nch] per-channel totals
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(NV == 16 ? 512 : 1024) void gn_fused_kernel(const P
     __syncthreads();
     }
     if (!active) return;
+    if (!AFFINE_EARLY) load_affine();
     float sa[8], sb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
