@@ -54,7 +54,7 @@ struct AttnCfg {
     // ASYNC: unconditional tile loads, padding applied at the LDS store (see the kernel).  Measured per shape on one box (round 4, us,
     // conditional / unconditional): 4096^2 dh 40 419 / 387, 1024^2 dh 40 32.8 / 29.4, 256^2 dh 80 11.1 / 9.8 - but 1024^2 dh 80 46.0 / 47.7
     // (one more live 128-bit register per thread: a wave of occupancy), 256^2 dh 160 14.0 / 14.7, one-tile cross-attention +1-2 %.
-    static constexpr int ASYNC = (KT == 64 && (DH < 80 || (DH == 80 && NWV == 4))) ? 1 : 0;
+    static constexpr int ASYNC = ((KT == 64 || KT == 128) && (DH < 80 || (DH == 80 && NWV == 4))) ? 1 : 0;
     static constexpr int KROW = DHP * 2 + 16;            // K tile row stride in bytes (pad: bank spread)
     // V tile stays ROW-MAJOR [key][d] and is read transposed by ds_read_b64_tr_b16 (gfx950).  A 32-lane half reads 8
     // consecutive key rows x 4 column quads: conflict-free when the row stride in dwords is 8 * odd.
@@ -192,34 +192,59 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
         if (C::ONES && key0 + r < Tk && c * 8 == DH) d.x = 0x3F80u;       // bf16 1.0 in column DH
         return d;
     };
+    // registers -> LDS: K tile [KT][DHP] and V tile [KT][DVP], both row-major and zero padded
+    auto stage = [&](char* kd, char* vd, int key0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
+            if (idx < KCHUNKS) *(u32x4v*)(kd + r * C::KROW + c * 16) = kfix(i, key0);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
+            if (idx < VCHUNKS) *(u32x4v*)(vd + r * C::VROW + c * 16) = vfix(i, key0);
+        }
+    };
+    // DB: two tile buffers - tile t + 1 is stored while tile t is consumed, ONE barrier per tile
+#ifdef MKD_ATTN_DB
+    constexpr bool DB = C::OFFS != 0;
+#else
+    constexpr bool DB = false;
+#endif
+    constexpr int TILE_BYTES = C::KBYTES + C::VBYTES;
     prefetch(0);
+    if (DB) {
+        stage(smem, smem + C::KBYTES, 0);
+        if (ntiles > 1) prefetch(KT);
+    }
 #ifdef MKD_ATTN_TRACE
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
 #endif
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
+        if (DB) { ks = smem + (t & 1) * TILE_BYTES; vs = ks + C::KBYTES; }
         ATT_T(6);
-        __syncthreads();                                   // previous tile fully consumed
+        __syncthreads();                                   // previous tile fully consumed (DB: and this tile stored by everyone)
         ATT_T(0);
-        // ---- registers -> LDS: K tile [64][DHP] and V tile [64][DVP], both row-major and zero padded ----
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int idx = tid + i * NT;
-            const int r = idx / (C::DHP / 8), c = idx - r * (C::DHP / 8);
-            if (idx < KCHUNKS) *(u32x4v*)(ks + r * C::KROW + c * 16) = kfix(i, key0);
+        if (DB) {
+            if (t + 1 < ntiles) {
+                char* const kn = smem + ((t + 1) & 1) * TILE_BYTES;
+                stage(kn, kn + C::KBYTES, key0 + KT);
+                ATT_T(1);
+                if (t + 2 < ntiles) prefetch(key0 + 2 * KT);
+            }
+            ATT_T(3);
+        } else {
+            stage(ks, vs, key0);
+            ATT_T(1);
+            __syncthreads();
+            ATT_T(2);
+            if (t + 1 < ntiles) prefetch(key0 + KT);       // in flight while this tile is consumed
+            ATT_T(3);
         }
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = tid + i * NT;
-            const int r = idx / (C::DVP / 8), c = idx - r * (C::DVP / 8);
-            if (idx < VCHUNKS) *(u32x4v*)(vs + r * C::VROW + c * 16) = vfix(i, key0);
-        }
-        ATT_T(1);
-        __syncthreads();
-        ATT_T(2);
-        if (t + 1 < ntiles) prefetch(key0 + KT);           // in flight while this tile is consumed
-        ATT_T(3);
 
         // ---- S^T[key][q] for KB key blocks of 16 ------------------------------------------------
         f32x4 st[KB];
@@ -409,6 +434,9 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     const bool wide = Tq >= 1024 && Tk >= 1024;             // long self-attention: 128 queries share each K/V tile
     static const bool kt96 = !(getenv("MKD_ATTN_KT96") && atoi(getenv("MKD_ATTN_KT96")) == 0);      // (A/B knob)
     const bool one96 = kt96 && !wide && !causal && Tk > 64 && Tk <= 96;      // cross-attention (77 context keys): one 96-key tile
+#ifndef MKD_ATTN_KT_WIDE
+#define MKD_ATTN_KT_WIDE 128     // keys per tile of the dh-40 long self-attention (round 4: 1024 keys 30.2 -> 28.6 us, 4096 keys equal; half the barriers per key)
+#endif
 #ifndef MKD_ATTN_OFFS_MIN
 #define MKD_ATTN_OFFS_MIN 1024
 #endif
@@ -437,7 +465,7 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
     } while (0)
 #define MKD_ATTN_CASE(D)                                                                                      \
     case D:                                                                                                   \
-        if (wide && msum == 2) MKD_ATTN_LAUNCH(D, 8, 64, 2);                                                  \
+        if (wide && msum == 2) MKD_ATTN_LAUNCH(D, 8, MKD_ATTN_KT_WIDE, 2);                                    \
         else if (wide && msum) MKD_ATTN_LAUNCH(D, 8, 64, 1);                                                  \
         else if (wide) MKD_ATTN_LAUNCH(D, 8, 64, 0);                                                          \
         else if (one96) MKD_ATTN_LAUNCH(D, 4, 96, 0);                                                         \
