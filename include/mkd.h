@@ -83,6 +83,8 @@ int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
  * give the initial values).  Takes effect at the next mkd_prepare (the launch plan is re-built).  Names:
  *   "tfm_tail"             fused row-local transformer tail: 0 off, 1 wherever the kernel covers the shape, -1 shape policy (default)
  *   "tfm_tail_min_rows"    ... the policy's threshold on the rows (samples x tokens) of a block (default 4096)
+ *   "tfm_head"             ... and the block's head (GroupNorm apply + proj_in + LayerNorm 1 . q|k|v) as one launch behind a GroupNorm
+ *                          statistics launch wherever the tail is fused: 0 off, 1 on (default)
  *   "gn_2k_min_hw"         GroupNorm over >= this many pixels per sample: two full-chip launches (default 4096)
  *   "xcd_auto_ratio"       XCD-aware tile order where M <= ratio x N (default 1; 0 = launch order everywhere)
  *   "dec_lanes"            decoder batch lanes 0 / 2 / 4 (default 2)
@@ -296,6 +298,14 @@ int  mkd_debug_attn_trace(long long* buf);      /* -DMKD_ATTN_TRACE builds: [wor
 int  mkd_tfm_tail_set_context(mkd_tfm_tail* h, const uint16_t* kv, int ldkv, int batch, int Tk, void* stream);
 int  mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_t* h0, int ldh, const uint16_t* xin, int ldx,
                       uint16_t* out, int ldo, int M, int T, void* stream);
+/* The head of the same block as ONE kernel behind a GroupNorm statistics launch: GroupNorm(32, eps) apply -> proj_in -> LayerNorm 1
+ * folded into to_q | to_k | to_v: x [B * T, d] (row stride ldx, T a multiple of 64) -> h0 [B * T, d] and qkv [B * T, 3d] (dense).
+ * fp32 DEVICE weights under their upstream shapes (SpatialTransformer.norm, .proj_in; transformer_blocks.0.norm1, attn1.to_q/k/v). */
+typedef struct mkd_tfm_head mkd_tfm_head;
+int  mkd_tfm_head_create(int d, const float* gn_g, const float* gn_b, const float* proj_in_w, const float* proj_in_b, const float* norm1_g,
+                         const float* norm1_b, const float* to_q_w, const float* to_k_w, const float* to_v_w, mkd_tfm_head** out);
+void mkd_tfm_head_destroy(mkd_tfm_head* h);
+int  mkd_tfm_head_run(mkd_tfm_head* h, const uint16_t* x, int ldx, float gn_eps, uint16_t* h0, uint16_t* qkv, int batch, int T, void* stream);
 /* LayerNorm over the last dim of [rows, d] bf16. */
 int mkd_layernorm(const uint16_t* x, const float* gamma, const float* beta, float eps,
                   uint16_t* y, int rows, int d, void* stream);

@@ -175,6 +175,10 @@ struct mkd_ctx {
     // the prepare plan).  tfm_tail: 0 off, 1 on where the kernel covers the shape, -1 (default) the shape policy of use_tfm_tail().
     int tfm_tail = getenv("MKD_TFM_TAIL") ? atoi(getenv("MKD_TFM_TAIL")) : -1;
     std::map<std::string, bf16_t*> tfm_w; std::map<std::string, float*> tfm_v; std::map<std::string, bf16_t*> tfm_kv;
+    // ... and the head of the same blocks (GroupNorm apply + proj_in + LayerNorm 1 . q|k|v as one launch behind a GroupNorm statistics
+    // launch: 4 launches -> 2): tfm_head 0 off, 1 wherever the tail is fused (default)
+    int tfm_head = getenv("MKD_TFM_HEAD") ? atoi(getenv("MKD_TFM_HEAD")) : 1;
+    std::map<std::string, bf16_t*> tfm_hw; std::map<std::string, float*> tfm_hv;
     std::map<std::string, float*> f32_keep;      // fp32 copies of the weights that get folded (kept for re-finalize)
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
@@ -511,7 +515,7 @@ struct mkd_ctx {
         }
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
         q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear(); ffm_w.clear(); ffm_b.clear();
-        tfm_w.clear(); tfm_v.clear();
+        tfm_w.clear(); tfm_v.clear(); tfm_hw.clear(); tfm_hv.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
@@ -609,6 +613,14 @@ struct mkd_ctx {
                     rc = tfm_tail_pack_weights(d, tw, (bf16_t*)wp, (float*)vp, 0);
                     if (rc) return rc;
                     tfm_w[p] = (bf16_t*)wp; tfm_v[p] = (float*)vp;
+                    void* hwp = nullptr; void* hvp = nullptr;
+                    rc = dev_alloc(&hwp, tfm_head_weight_bytes(d)); if (rc) return rc;
+                    rc = dev_alloc(&hvp, tfm_head_vec_bytes(d)); if (rc) return rc;
+                    TfmHeadWeights hw{wf(p + ".norm.weight"), wf(p + ".norm.bias"), wb(p + ".proj_in.weight"), wf(p + ".proj_in.bias"),
+                                      qkv_w.at(p), qkv_s.at(p), qkv_b.at(p)};
+                    rc = tfm_head_pack_weights(d, hw, (bf16_t*)hwp, (float*)hvp, 0);
+                    if (rc) return rc;
+                    tfm_hw[p] = (bf16_t*)hwp; tfm_hv[p] = (float*)hvp;
                 }
             }
             std::vector<std::string> wn;
@@ -841,6 +853,13 @@ struct mkd_ctx {
         return tfm_tail > 0 || M >= tfm_tail_min_rows;
     }
     int tfm_tail_min_rows = getenv("MKD_TFM_TAIL_MINROWS") ? atoi(getenv("MKD_TFM_TAIL_MINROWS")) : 4096;
+    void emit_tfm_tail(const std::string& p, int d, int M, int T, const bf16_t* a1, const bf16_t* h0, const Tensor& x, bf16_t* out, int ldo, int b0) {
+        const bf16_t* wpk = tfm_w.at(p); const float* vec = tfm_v.at(p);
+        const bf16_t* kvp = tfm_kv.at(p) + (size_t)b0 * (tfm_tail_kv_bytes(d, 1) / sizeof(bf16_t));
+        const bf16_t* xin = x.p; const int ldx = x.ld, Tk = ctx_len();
+        push(*cur_plan, [=](hipStream_t st) { return launch_tfm_tail(d, wpk, vec, a1, d, h0, d, xin, ldx, kvp, out, ldo, M, T, Tk, st); },
+             1, tfm_tail_flops(d, M, Tk), K_TFM_TAIL, "M=" + std::to_string(M) + " d=" + std::to_string(d) + " T=" + std::to_string(T));
+    }
     // SpatialTransformer, depth 1 (App. A.2). x: [B,H,W,d] contiguous or strided. Writes at (out, ldo).
     // b0: first sample of x inside the prepared batch (decoder lanes run on a batch slice; the cross-attention K/V cache is
     // indexed by absolute sample)
@@ -849,6 +868,28 @@ struct mkd_ctx {
         const int d = x.C, M = x.rows(), T = x.H * x.W, heads = cfg.num_heads, dh = d / heads;
         const std::string t = p + ".transformer_blocks.0";
         auto buf = [&](int cols) { return (bf16_t*)TA().alloc((size_t)M * cols * sizeof(bf16_t)); };
+        const bool fused_tail = use_tfm_tail(p, d, M, T, fuse_ln && gemm_stat_slots(M, d, d) <= 20, go);
+        if (fused_tail && tfm_head != 0 && tfm_hw.count(p) && !x.gst) {
+            // head as two launches: GroupNorm statistics (full chip), then GroupNorm apply + proj_in + LayerNorm 1 . q|k|v per 64-token tile
+            bf16_t* h0f = buf(d); bf16_t* qkvf = buf(3 * d);
+            const size_t need = groupnorm_partials_bytes(x.B, T, 32);
+            if (need > gn_need) gn_need = need;
+            mkd_ctx* self = this;
+            const int sid = cur_sid;
+            const Tensor xt = x;
+            const bf16_t* hwp = tfm_hw.at(p); const float* hvp = tfm_hv.at(p);
+            push(*cur_plan, [self, xt, T, d, sid, hwp, hvp, h0f, qkvf, M](hipStream_t st) {
+                int nch = 0;
+                int rc = launch_gn_stats(xt.p, xt.ld, xt.B, T, d, 32, self->gn_ws[arena_of(sid)], st, &nch);
+                if (rc) return rc;
+                return launch_tfm_head(d, hwp, hvp, xt.p, xt.ld, self->gn_ws[arena_of(sid)], nch, 1e-6f, h0f, qkvf, M, T, st);
+            }, 2, 2.0 * M * 4.0 * d * d, K_TFM_TAIL, "head M=" + std::to_string(M) + " d=" + std::to_string(d) + " T=" + std::to_string(T));
+            bf16_t* a1f = buf(d);
+            op_attn(qkvf, 3 * d, qkvf + d, 3 * d, qkvf + 2 * d, 3 * d, a1f, d, x.B, T, T, heads, dh);
+            emit_tfm_tail(p, d, M, T, a1f, h0f, x, out, ldo, b0);
+            TA().release(mk);
+            return;
+        }
         bf16_t* g = buf(d);
         op_gn(x, wf(p + ".norm.weight"), wf(p + ".norm.bias"), 1e-6f, 0, g, d);
         // Two variants.  fuse_ln: LayerNorm1/2/3 never run as kernels - the GEMM that PRODUCES h0/h1/h2 emits per-column-
@@ -880,12 +921,8 @@ struct mkd_ctx {
           op_linear(a_in, d, M, d, f ? qkv_w.at(p) : qkv_plain.at(p), 3 * d, e, qkv, 3 * d); }
         bf16_t* a1 = buf(d);
         op_attn(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, a1, d, x.B, T, T, heads, dh);
-        if (use_tfm_tail(p, d, M, T, fl, go)) {          // everything below as one launch per 64-token tile
-            const bf16_t* wpk = tfm_w.at(p); const float* vec = tfm_v.at(p);
-            const bf16_t* kvp = tfm_kv.at(p) + (size_t)b0 * (tfm_tail_kv_bytes(d, 1) / sizeof(bf16_t));
-            const bf16_t* xin = x.p; const int ldx = x.ld, Tk = ctx_len();
-            push(*cur_plan, [=](hipStream_t st) { return launch_tfm_tail(d, wpk, vec, a1, d, h0, d, xin, ldx, kvp, out, ldo, M, T, Tk, st); },
-                 1, tfm_tail_flops(d, M, Tk), K_TFM_TAIL, "M=" + std::to_string(M) + " d=" + std::to_string(d) + " T=" + std::to_string(T));
+        if (fused_tail) {          // everything below as one launch per 64-token tile
+            emit_tfm_tail(p, d, M, T, a1, h0, x, out, ldo, b0);
             TA().release(mk);
             return;
         }
@@ -2442,6 +2479,7 @@ int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value) {
     const int iv = (int)value;
     if (n == "tfm_tail") ctx->tfm_tail = iv;
     else if (n == "tfm_tail_min_rows") ctx->tfm_tail_min_rows = iv;
+    else if (n == "tfm_head") ctx->tfm_head = iv;
     else if (n == "gn_2k_min_hw") ctx->gn_2k_min_hw = iv;
     else if (n == "xcd_auto_ratio") ctx->xcd_auto_ratio = (float)value;
     else if (n == "dec_lanes") { if (iv != 0 && iv != 2 && iv != 4) return mkd_fail(MKD_ERR_ARG, "dec_lanes: 0, 2 or 4"); ctx->dec_lanes = iv; }
@@ -2457,6 +2495,7 @@ int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value) {
     const std::string n(name);
     if (n == "tfm_tail") *value = ctx->tfm_tail;
     else if (n == "tfm_tail_min_rows") *value = ctx->tfm_tail_min_rows;
+    else if (n == "tfm_head") *value = ctx->tfm_head;
     else if (n == "gn_2k_min_hw") *value = ctx->gn_2k_min_hw;
     else if (n == "xcd_auto_ratio") *value = ctx->xcd_auto_ratio;
     else if (n == "dec_lanes") *value = ctx->dec_lanes;
@@ -2750,6 +2789,51 @@ int mkd_tfm_tail_run(mkd_tfm_tail* h, const uint16_t* a1, int lda, const uint16_
     if (!h || !h->kvp) return mkd_fail(MKD_ERR_STATE, "tfm_tail: set the context first");
     if (T <= 0 || M % T || M / T > h->kv_batch) return mkd_fail(MKD_ERR_ARG, "tfm_tail: M must be samples x T within the packed context");
     return launch_tfm_tail(h->d, h->wpk, h->vec, a1, lda, h0, ldh, xin, ldx, h->kvp, out, ldo, M, T, h->Tk, (hipStream_t)stream);
+}
+
+// ---- fused transformer head, stand-alone (unit parity test) ---------------------------------------------------------------------
+struct mkd_tfm_head { int d = 0; bf16_t* wpk = nullptr; float* vec = nullptr; float* part = nullptr; size_t part_bytes = 0; std::vector<void*> owned; };
+void mkd_tfm_head_destroy(mkd_tfm_head* h) {
+    if (!h) return;
+    for (void* p : h->owned) hipFree(p);
+    delete h;
+}
+int mkd_tfm_head_create(int d, const float* gn_g, const float* gn_b, const float* proj_in_w, const float* proj_in_b, const float* norm1_g,
+                        const float* norm1_b, const float* to_q_w, const float* to_k_w, const float* to_v_w, mkd_tfm_head** out) {
+    if (!out) return mkd_fail(MKD_ERR_ARG, "null out");
+    if (!tfm_head_weight_bytes(d)) return mkd_fail(MKD_ERR_UNSUPPORTED, "tfm_head: only d = 320 is built");
+    mkd_tfm_head* h = new mkd_tfm_head; h->d = d;
+    auto dal = [&](size_t bytes, void** o) -> int { MKD_HIP_CHECK(hipMalloc(o, bytes)); h->owned.push_back(*o); return 0; };
+    void *wpi = nullptr, *wq = nullptr, *sq = nullptr, *bq = nullptr;
+    const size_t dd = (size_t)d * d;
+    int rc = dal(dd * 2, &wpi);
+    if (!rc) rc = dal(3 * dd * 2, &wq); if (!rc) rc = dal(3 * d * 4, &sq); if (!rc) rc = dal(3 * d * 4, &bq);
+    if (!rc) rc = dal(tfm_head_weight_bytes(d), (void**)&h->wpk);
+    if (!rc) rc = dal(tfm_head_vec_bytes(d), (void**)&h->vec);
+    if (!rc) rc = launch_f32_to_bf16(proj_in_w, (bf16_t*)wpi, (int64_t)dd, 0);
+    const float* parts[3] = {to_q_w, to_k_w, to_v_w};
+    for (int j = 0; j < 3 && !rc; ++j)
+        rc = launch_fold_layernorm(parts[j], norm1_g, norm1_b, nullptr, d, d, (bf16_t*)wq, j * d, 1, (float*)sq, (float*)bq, 0);
+    if (!rc) {
+        TfmHeadWeights s{gn_g, gn_b, (const bf16_t*)wpi, proj_in_b, (const bf16_t*)wq, (const float*)sq, (const float*)bq};
+        rc = tfm_head_pack_weights(d, s, h->wpk, h->vec, 0);
+    }
+    if (rc) { mkd_tfm_head_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+int mkd_tfm_head_run(mkd_tfm_head* h, const uint16_t* x, int ldx, float gn_eps, uint16_t* h0, uint16_t* qkv, int batch, int T, void* stream) {
+    if (!h) return mkd_fail(MKD_ERR_ARG, "null handle");
+    const size_t need = groupnorm_partials_bytes(batch, T, 32);
+    if (need > h->part_bytes) {
+        void* p = nullptr;
+        MKD_HIP_CHECK(hipMalloc(&p, need));
+        h->owned.push_back(p); h->part = (float*)p; h->part_bytes = need;
+    }
+    int nch = 0;
+    int rc = launch_gn_stats(x, ldx, batch, T, h->d, 32, h->part, (hipStream_t)stream, &nch);
+    if (rc) return rc;
+    return launch_tfm_head(h->d, h->wpk, h->vec, x, ldx, h->part, nch, gn_eps, h0, qkv, batch * T, T, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -657,6 +657,25 @@ size_t groupnorm_partials_bytes(int batch, int hw, int groups) {
     return (size_t)batch * gn_chunks(hw) * groups * 2 * sizeof(float);
 }
 
+// first half of the two-launch GroupNorm on its own: per (sample, row chunk, group) partial (sum, sum of squares) ->
+// partials[(b * nchunks + chunk) * groups + g][2]; full-chip grid.  Also the producer of the statistics tfm_head_kernel applies.
+int launch_gn_stats(const bf16_t* x, int ld_in, int batch, int hw, int C, int groups, float* partials, hipStream_t stream, int* nchunks_out) {
+    if (C % 8 || ld_in % 8 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return mkd_fail(-1, "gn_stats: bad geometry");
+    if (!partials) return mkd_fail(-1, "gn_stats: partials workspace missing");
+    const int V = C / 8;
+    if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");
+    int P = 256 / V;
+    if (P < 1) P = 1;
+    const int threads = V * P;
+    const int nchunks = gn_chunks(hw);
+    const int rows_per_chunk = (hw + nchunks - 1) / nchunks;
+    dim3 grid(nchunks, batch);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)threads * 16 * sizeof(float), stream, x, ld_in, hw, C, groups, rows_per_chunk, partials);
+    MKD_LAUNCH_CHECK("gn_stats_kernel");
+    if (nchunks_out) *nchunks_out = nchunks;
+    return 0;
+}
+
 int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu,
                      bf16_t* y, int ld_out, int batch, int hw, int C, int groups, float* partials,
                      hipStream_t stream, const NormIo* second, int two_kernel_min_hw) {
@@ -705,16 +724,15 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
         if (rc) return rc;
         return launch_groupnorm(second->x, ld_in, second->gamma, second->beta, eps, silu, second->y, ld_out, batch, hw, C, groups, partials, stream, nullptr, two_kernel_min_hw);
     }
+    int nchunks = 0;
+    int rc0 = launch_gn_stats(x, ld_in, batch, hw, C, groups, partials, stream, &nchunks);
+    if (rc0) return rc0;
     const int V = C / 8;
-    if (V > 1024) return mkd_fail(-4, "groupnorm: C > 8192 unsupported");
     int P = 256 / V;
     if (P < 1) P = 1;
     const int threads = V * P;
-    const int nchunks = gn_chunks(hw);
     const int rows_per_chunk = (hw + nchunks - 1) / nchunks;
     dim3 grid(nchunks, batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)threads * 16 * sizeof(float), stream, x, ld_in, hw, C, groups, rows_per_chunk, partials);
-    MKD_LAUNCH_CHECK("gn_stats_kernel");
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, x, ld_in, y, ld_out, gamma, beta, eps, silu,
                        hw, C, groups, rows_per_chunk, nchunks, partials);
     MKD_LAUNCH_CHECK("gn_apply_kernel");

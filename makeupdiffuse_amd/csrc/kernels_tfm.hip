@@ -33,6 +33,7 @@
 // block output out.  Measured (profiles/exp_r4_tfm_*): 67 us per workgroup generation alone on the chip against
 // 94 us for the 7 launches at 8192 rows, 146 against 302 us at 32768; in the loop +4 % (batch 8) to +7 % (interpolation batch).
 #include "mkd_common.h"
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -539,6 +540,201 @@ __global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs
     else tfm_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
 }
 
+// ---- the head of the block: GroupNorm apply + proj_in + LayerNorm 1 . (q | k | v) ----------------------------------------------------
+// Same machinery as the tail (weights packed in consumption order -> registers of one wave, activations in LDS in operand order).
+// The GroupNorm statistics come from a full-chip statistics launch (launch_gn_stats: partial sums per row chunk); the workgroup
+// finishes them for its sample, normalises its x tile on the way into LDS, and writes h0 (the tail's residual) and q | k | v.
+template <int D>
+struct TfmHeadCfg {
+    using T = TfmCfg<D>;
+    static constexpr int OFF_PI = 0, OFF_QKV = T::NFR * T::KSD, UNITS = 4 * T::NFR * T::KSD;      // proj_in, then the q, k, v thirds
+    static constexpr int V_BPI = 0, V_S = D, V_B = 4 * D, V_G = 7 * D, V_BETA = 8 * D, V_TOTAL = 9 * D;
+    static constexpr int ST_OFF = 2 * T::BUF;                      // LayerNorm 1 partials [waves][tokens] float2
+    static constexpr int VEC_OFF = ST_OFF + TFM_NW * TFM_TM * 8;
+    static constexpr int AB_OFF = VEC_OFF + V_TOTAL * 4;           // GroupNorm scale / shift per channel [D] float2
+    static constexpr int GS_OFF = AB_OFF + D * 8;                  // GroupNorm (mean, rstd) per group [32] float2
+    static constexpr int PF_OFF = GS_OFF + 32 * 8;                 // 256 B per wave: landing pad of the L2 warm-up loads
+    static constexpr int LDS = PF_OFF + TFM_NW * 256;
+};
+
+struct TfmHeadArgs {
+    const bf16x8* wpk; const float* vec;
+    const bf16_t* x; int ldx;
+    const float* part; int nchunks; float gn_eps;       // GroupNorm partials [(b * nchunks + chunk) * 32 + g][2]
+    bf16_t* h0; bf16_t* qkv;
+    int T;
+};
+
+// one third (q, k or v: N = D output channels) of the LayerNorm-folded projection, written straight to global
+template <int D, int NFN, bool NEXT>
+__device__ __forceinline__ void head_third(const int t, Ring<NFN>& cur, Ring<NFN>& nxt, const WStream& ws, const WStream& wn, unsigned lo,
+                                           const char* xb, int xs, const float* vec, const float (&mean)[TFM_MF], const float (&rstd)[TFM_MF],
+                                           bf16_t* qkv, int row0, int fr0, int r, int g) {
+    using C = TfmCfg<D>;
+    using H = TfmHeadCfg<D>;
+    f32x4 acc[NFN][TFM_MF];
+    zero_acc<NFN>(acc);
+    stage_mm<NFN, C::KSD, NEXT, NFN>(cur, ws, nxt, wn, lo, xb, xs, acc);
+#pragma unroll
+    for (int f = 0; f < NFN; ++f) {
+        const int n = 16 * (fr0 + f) + 4 * g;
+        float sv[4], bv[4];
+        ld4(vec + H::V_S + t * D + n, sv); ld4(vec + H::V_B + t * D + n, bv);
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) {
+            U16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = f32_to_bf16(rstd[mf] * (acc[f][mf][i] - mean[mf] * sv[i]) + bv[i]);
+            *(U16x4*)(qkv + (size_t)(row0 + 16 * mf + r) * (3 * D) + t * D + n) = o;
+        }
+    }
+}
+
+template <int D, int NFN>
+__device__ __forceinline__ void tfm_head_wave(const TfmHeadArgs& a, char* smem, const int w, const int lane, const int fr0) {
+    using C = TfmCfg<D>;
+    using H = TfmHeadCfg<D>;
+    const int tid = w * 64 + lane;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * TFM_TM;
+    const int b = row0 / a.T;
+    char* const bufA = smem;
+    char* const bufB = smem + C::BUF;
+    float2* const st1 = (float2*)(smem + H::ST_OFF);
+    const float* const vec = (const float*)(smem + H::VEC_OFF);
+    float2* const ab = (float2*)(smem + H::AB_OFF);
+    float2* const gs = (float2*)(smem + H::GS_OFF);
+    const int xs = C::KSD * 1024;
+    const unsigned lo = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wpk, (unsigned)H::UNITS * 1024u);
+    const WStream w_pi{wrs, (H::OFF_PI + C::KSD * fr0) * 1024};
+    auto w_third = [&](int t) { return WStream{wrs, (H::OFF_QKV + t * C::NFR * C::KSD + C::KSD * fr0) * 1024}; };
+    auto out_off = [&](int mf, int fr) { return lds_chunk(mf, 2 * fr + (g >> 1), r, C::KSD) + (g & 1) * 8; };
+
+    Ring<NFN> ring0, ring1;
+    ring_fill<NFN>(ring0, w_pi, lo);
+    // x tile -> registers in operand order (chunk idx = block (mf, ks) * 64 + (g, r)); vectors -> LDS by LDS-DMA
+    constexpr int PER = TFM_MF * C::KSD / TFM_NW;
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v xr[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int blk = w + i * TFM_NW, mf = blk / C::KSD, ks = blk - mf * C::KSD;
+        xr[i] = *(const u32x4v*)(a.x + (size_t)(row0 + 16 * mf + r) * a.ldx + 32 * ks + 8 * g);
+    }
+    {
+        constexpr int NV16 = H::V_TOTAL / 4;
+        const float4* src = (const float4*)a.vec;
+        for (int i = w * 64; i < NV16; i += TFM_NW * 64)
+            if (i + lane < NV16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i + lane),
+                                                 (__attribute__((address_space(3))) void*)(smem + H::VEC_OFF + i * 16), 16, 0, 0);
+    }
+    // GroupNorm statistics of this sample: thread (slice = tid / 32, group = tid % 32) sums the partials of row chunks slice,
+    // slice + 16, ... (at most 4: launch_gn_stats cuts a sample into <= 64 chunks; all loads in flight at once, fixed order), then
+    // 32 threads add the 16 slices in order
+    float2* const red = (float2*)bufB;                      // [16][32], free until S1's epilogue
+    {
+        const int sl = tid >> 5, gi = tid & 31;
+        float2 pp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = sl + 16 * i;
+            pp[i] = *(const float2*)(a.part + ((size_t)(b * a.nchunks + (c < a.nchunks ? c : 0)) * 32 + gi) * 2);
+        }
+        // L2 warm-up of the weight stream, split among the workgroups of an XCD as in tfm_prologue
+        {
+            char* pad = smem + H::PF_OFF + w * 256;
+            const int nsl = min(16, max(1, (int)gridDim.x >> 3)), sx = ((int)blockIdx.x >> 3) % nsl;
+            const char* base = (const char*)a.wpk + lane * 64;
+            for (int q = sx + nsl * w; q < H::UNITS / 4; q += nsl * TFM_NW) warm64(base + (size_t)q * 4096, pad);
+        }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (sl + 16 * i < a.nchunks) { s += pp[i].x; q += pp[i].y; }
+        red[sl * 32 + gi] = make_float2(s, q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // vectors landed in LDS (LDS-DMA completes on vmcnt)
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float2 v = red[i * 32 + tid]; s += v.x; q += v.y; }
+        const float n = (float)a.T * (float)(D / 32);
+        const float mean = s / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        gs[tid] = make_float2(mean, rsqrtf(var + a.gn_eps));
+    }
+    __syncthreads();
+    if (tid < D) {                                          // per channel: y = x * a + b
+        const float2 ms = gs[tid / (D / 32)];
+        const float sc = vec[H::V_G + tid] * ms.y;
+        ab[tid] = make_float2(sc, vec[H::V_BETA + tid] - ms.x * sc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int blk = w + i * TFM_NW, ks = blk % C::KSD;
+        const int c0 = 32 * ks + 8 * g;
+        U16x8 t = __builtin_bit_cast(U16x8, xr[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float2 p = ab[c0 + j]; t.v[j] = f32_to_bf16(bf16_to_f32(t.v[j]) * p.x + p.y); }
+        *(U16x8*)(bufA + (blk * 64 + lane) * 16) = t;
+    }
+    __syncthreads();
+
+    // ---- S1: h0 = proj_in(g) -> bufB and global, LayerNorm 1 partials -> st1 -------------------------------------------------
+    {
+        f32x4 acc[NFN][TFM_MF];
+        zero_acc<NFN>(acc);
+        stage_mm<NFN, C::KSD, true, NFN>(ring0, w_pi, ring1, w_third(0), lo, bufA + lane * 16, xs, acc);
+        float s[TFM_MF], q[TFM_MF];
+#pragma unroll
+        for (int mf = 0; mf < TFM_MF; ++mf) { s[mf] = 0.f; q[mf] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < NFN; ++f) {
+            const int n = 16 * (fr0 + f) + 4 * g;
+            float bv[4]; ld4(vec + H::V_BPI + n, bv);
+#pragma unroll
+            for (int mf = 0; mf < TFM_MF; ++mf) {
+                U16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o.v[i] = f32_to_bf16(acc[f][mf][i] + bv[i]);
+                    const float vr = bf16_to_f32(o.v[i]);
+                    s[mf] += vr; q[mf] += vr * vr;
+                }
+                *(U16x4*)(bufB + out_off(mf, fr0 + f)) = o;
+                *(U16x4*)(a.h0 + (size_t)(row0 + 16 * mf + r) * D + n) = o;
+            }
+        }
+        put_stats(s, q, st1, w, r, g);
+    }
+    __syncthreads();
+    // ---- S2: q | k | v = LN1(h0) . W'^T, one third (N = D) at a time; straight to global ------------------------------------
+    {
+        float mean[TFM_MF], rstd[TFM_MF];
+        get_stats<D>(st1, r, mean, rstd);
+        // (no barrier separates the thirds: without the scheduling fences the compiler hoists the later thirds' weight loads to the
+        // front and spills 60 registers)
+        head_third<D, NFN, true>(0, ring1, ring0, w_third(0), w_third(1), lo, bufB + lane * 16, xs, vec, mean, rstd, a.qkv, row0, fr0, r, g);
+        __builtin_amdgcn_sched_barrier(0);
+        head_third<D, NFN, true>(1, ring0, ring1, w_third(1), w_third(2), lo, bufB + lane * 16, xs, vec, mean, rstd, a.qkv, row0, fr0, r, g);
+        __builtin_amdgcn_sched_barrier(0);
+        head_third<D, NFN, false>(2, ring1, ring0, w_third(2), w_third(2), lo, bufB + lane * 16, xs, vec, mean, rstd, a.qkv, row0, fr0, r, g);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * TFM_NW) void tfm_head_kernel(const TfmHeadArgs a) {
+    using C = TfmCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (C::NWA == TFM_NW || w < C::NWA) tfm_head_wave<D, C::NFA>(a, smem, w, lane, w * C::NFA);
+    else tfm_head_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
+}
+
 // ---- packing ---------------------------------------------------------------------------------------------------------------
 // one 1 KiB unit per block: out[u][lane][j] = W[rows[u][lane & 15]][32 ks[u] + 8 (lane >> 4) + j]
 __global__ void tfm_pack_units_kernel(const bf16_t* __restrict__ W, int ldw, const int* __restrict__ tab, bf16_t* __restrict__ out) {
@@ -688,5 +884,62 @@ int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1
     }
     hipLaunchKernelGGL(tfm_tail_kernel<320>, dim3(M / TFM_TM), dim3(64 * TFM_NW), C::LDS, stream, a);
     MKD_LAUNCH_CHECK("tfm_tail_kernel");
+    return 0;
+}
+
+size_t tfm_head_weight_bytes(int d) { return d == 320 ? (size_t)TfmHeadCfg<320>::UNITS * 1024 : 0; }
+size_t tfm_head_vec_bytes(int d) { return d == 320 ? (size_t)TfmHeadCfg<320>::V_TOTAL * sizeof(float) : 0; }
+
+int tfm_head_pack_weights(int d, const TfmHeadWeights& s, bf16_t* wpk, float* vec, hipStream_t stream) {
+    if (d != 320) return mkd_fail(-4, "tfm_head: only d = 320 is built");
+    using C = TfmCfg<320>; using H = TfmHeadCfg<320>;
+    constexpr int D = 320;
+    std::vector<void*> tmp;
+    auto first_frag = [](int w) { return w < C::NWA ? w * C::NFA : C::NWA * C::NFA + (w - C::NWA) * C::NFB; };
+    auto nfrag = [](int w) { return w < C::NWA ? C::NFA : C::NFB; };
+    auto plain = [&](int row0) {
+        std::vector<int> tab;
+        for (int w = 0; w < TFM_NW; ++w)
+            for (int ks = 0; ks < C::KSD; ++ks)
+                for (int f = 0; f < nfrag(w); ++f) {
+                    for (int i = 0; i < 16; ++i) tab.push_back(row0 + 16 * (first_frag(w) + f) + i);
+                    tab.push_back(ks);
+                }
+        return tab;
+    };
+    int rc = pack_stage<D>(s.w_pi, D, plain(0), wpk + (size_t)H::OFF_PI * 512, stream, tmp);
+    for (int t = 0; t < 3 && !rc; ++t)
+        rc = pack_stage<D>(s.w_qkv, D, plain(t * D), wpk + (size_t)(H::OFF_QKV + t * C::NFR * C::KSD) * 512, stream, tmp);
+    auto cp = [&](int off, const float* src, int n) { return hipMemcpyAsync(vec + off, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, stream); };
+    if (!rc) {
+        MKD_HIP_CHECK(cp(H::V_BPI, s.b_pi, D));
+        MKD_HIP_CHECK(cp(H::V_S, s.s_qkv, 3 * D));
+        MKD_HIP_CHECK(cp(H::V_B, s.b_qkv, 3 * D));
+        MKD_HIP_CHECK(cp(H::V_G, s.gn_gamma, D));
+        MKD_HIP_CHECK(cp(H::V_BETA, s.gn_beta, D));
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    for (void* p : tmp) (void)hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) return mkd_fail(-2, std::string("tfm_head pack: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int launch_tfm_head(int d, const bf16_t* wpk, const float* vec, const bf16_t* x, int ldx, const float* gn_partials, int gn_chunks, float gn_eps,
+                    bf16_t* h0, bf16_t* qkv, int M, int T, hipStream_t stream) {
+    if (d != 320 || T <= 0 || T % TFM_TM || M <= 0 || M % T) return mkd_fail(-4, "tfm_head: unsupported shape");
+    if (ldx % 8 || gn_chunks <= 0 || gn_chunks > 64 || !gn_partials) return mkd_fail(-1, "tfm_head: x stride must be a multiple of 8; GroupNorm partials of <= 64 row chunks required");
+    using H = TfmHeadCfg<320>;
+    TfmHeadArgs a;
+    a.wpk = (const bf16x8*)wpk; a.vec = vec; a.x = x; a.ldx = ldx; a.part = gn_partials; a.nchunks = gn_chunks; a.gn_eps = gn_eps;
+    a.h0 = h0; a.qkv = qkv; a.T = T;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)tfm_head_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, H::LDS);
+        if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(tfm_head LDS): ") + hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(tfm_head_kernel<320>, dim3(M / TFM_TM), dim3(64 * TFM_NW), H::LDS, stream, a);
+    MKD_LAUNCH_CHECK("tfm_head_kernel");
     return 0;
 }

@@ -153,6 +153,7 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                      hipStream_t stream, const NormIo* second = nullptr,       // second: same geometry, grouped launch
                      int two_kernel_min_hw = 1 << 30);      // >= this many pixels per sample: the two full-chip launches (mkd_ctx::gn_2k_min_hw)
 size_t groupnorm_partials_bytes(int batch, int hw, int groups);
+int launch_gn_stats(const bf16_t* x, int ld_in, int batch, int hw, int C, int groups, float* partials, hipStream_t stream, int* nchunks_out);
 // GroupNorm with producer-emitted statistics (gstat[batch][32][2] int64 fixed point, see gemm_device.h): element-wise apply,
 // and the stand-alone producer of the same statistics for tensors whose writer cannot emit them
 int launch_gn_apply_stats(const bf16_t* x, int ld_in, const float* gamma, const float* beta, float eps, int silu, bf16_t* y, int ld_out,
@@ -182,6 +183,18 @@ struct TfmTailWeights {
     const bf16_t* w_g; const float* s_g; const float* b_g;
     const bf16_t* w_m; const float* b_m;
 };
+// ---- fused head of a d = 320 SpatialTransformer (kernels_tfm.hip): GroupNorm apply (statistics from launch_gn_stats) + proj_in +
+// LayerNorm 1 folded into the q | k | v projection, one launch per 64-token tile: h0 [M, d] and qkv [M, 3d] out
+struct TfmHeadWeights {
+    const float* gn_gamma; const float* gn_beta;
+    const bf16_t* w_pi; const float* b_pi;                       // proj_in [d][d]
+    const bf16_t* w_qkv; const float* s_qkv; const float* b_qkv; // [3d][d] folded with LayerNorm 1 (W' = W diag(gamma), s, b')
+};
+size_t tfm_head_weight_bytes(int d);
+size_t tfm_head_vec_bytes(int d);
+int tfm_head_pack_weights(int d, const TfmHeadWeights& src, bf16_t* wpk, float* vec, hipStream_t stream);       // synchronous
+int launch_tfm_head(int d, const bf16_t* wpk, const float* vec, const bf16_t* x, int ldx, const float* gn_partials, int gn_chunks, float gn_eps,
+                    bf16_t* h0, bf16_t* qkv, int M, int T, hipStream_t stream);
 void   tfm_tail_set_trace(long long* buf);
 bool   tfm_tail_supported(int d, int heads, int T, int Tk);      // T tokens per sample, Tk context keys
 size_t tfm_tail_weight_bytes(int d);

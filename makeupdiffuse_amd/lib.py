@@ -102,6 +102,9 @@ SIGNATURES = {
     'mkd_tfm_tail_destroy': (None, [_P]),
     'mkd_tfm_tail_set_context': (_I, [_P, _P, _I, _I, _I, _P]),
     'mkd_tfm_tail_run': (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    'mkd_tfm_head_create': (_I, [_I] + [_P] * 9 + [C.POINTER(_P)]),
+    'mkd_tfm_head_destroy': (None, [_P]),
+    'mkd_tfm_head_run': (_I, [_P, _P, _I, _F, _P, _P, _I, _I, _P]),
     'mkd_layernorm': (_I, [_P, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_layernorm_ld': (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _P]),
     'mkd_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -84,7 +84,7 @@ def test_full_size_fused_transformer_tail_equals_the_seven_launch_plan(full):
             e.prepare(I['hint'], I['ctx'])
         a_def, a_off, a_on = eng.eps(I['x'], I['t']), off.eps(I['x'], I['t']), on.eps(I['x'], I['t'])
         assert torch.equal(a_def, a_on)                      # batch 8 is inside the default policy
-        assert off.eps_launches() - on.eps_launches() == 60, (off.eps_launches(), on.eps_launches())      # 10 fused blocks x 6 launches
+        assert off.eps_launches() - on.eps_launches() == 80, (off.eps_launches(), on.eps_launches())      # 10 fused blocks x (7 -> 1 tail, 4 -> 2 head)
         r8 = rel(a_on, a_off)
         sch = DDIMSchedule().make_ddim(10)
         args = (sch.ddim_timesteps, sch.ddim_alphas, sch.ddim_alphas_prev, sch.ddim_sqrt_one_minus_alphas)
@@ -94,7 +94,7 @@ def test_full_size_fused_transformer_tail_equals_the_seven_launch_plan(full):
         for e in (off, on):
             e.prepare(I['hint'][:1], I['ctx'][:1])
         r1 = rel(on.eps(I['x'][:1], I['t'][:1]), off.eps(I['x'][:1], I['t'][:1]))
-        assert off.eps_launches() - on.eps_launches() == 35      # batch 1: no decoder lanes, 7 blocks x (6 - 1): LayerNorm 3 is on the fly there
+        assert off.eps_launches() - on.eps_launches() == 42      # batch 1: no decoder lanes, 7 blocks x ((6 - 1) + (3 - 2)): LayerNorms 1 and 3 are on the fly there
         g = torch.Generator().manual_seed(11)
         x = torch.randn(2, 4, 64, 64, generator=g); hint = torch.rand(2, 6, 512, 512, generator=g); ctx = torch.randn(2, 77, 768, generator=g)
         t = torch.tensor([901, 101])
@@ -106,6 +106,18 @@ def test_full_size_fused_transformer_tail_equals_the_seven_launch_plan(full):
         # bf16 plans of these nets (batch 8 vs 3 + 5: same budget above); against the fp32 oracle both plans sit at 1.48e-2 / 1.49e-2
         # (tests/test_gpu_engine.py::test_full_size_eps_vs_oracle)
         assert max(r8, r1, r512) <= 2e-2 and rl <= 1e-2
+        # the head of the same blocks (GroupNorm apply + proj_in + LayerNorm 1 . q|k|v as one launch behind a statistics launch) is its
+        # own switch: off, the 10 blocks run GroupNorm, proj_in, LayerNorm, q|k|v again (measured 8.6e-3 between the two)
+        n_on = None
+        for hd in (1, 0):
+            on.set_option('tfm_head', hd)
+            on.prepare(I['hint'], I['ctx'])
+            a = on.eps(I['x'], I['t'])
+            if hd: assert torch.equal(a, a_on); n_on = on.eps_launches()
+            else:
+                rh = rel(a_on, a)
+                print(f'fused head vs 4 launches: eps batch 8 rel-L2 {rh:.3e}')
+                assert on.eps_launches() - n_on == 20 and rh <= 2e-2
     finally:
         off.close(); on.close()
 

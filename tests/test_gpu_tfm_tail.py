@@ -113,3 +113,40 @@ def test_tfm_tail_rejects_shapes_it_does_not_cover():
         assert L().mkd_tfm_tail_create(640, *[P(dev[k]) for k in ORDER], C.byref(hh)) != 0         # only d = 320 is built
     finally:
         L().mkd_tfm_tail_destroy(h)
+
+
+@pytest.mark.parametrize('B,T,pad', [(1, 64, 0), (2, 1024, 0), (3, 256, 64), (2, 4096, 0)])
+def test_tfm_head_matches_the_torch_fp32_chain(B, T, pad):
+    """The head of the block as one kernel behind a GroupNorm statistics launch: GroupNorm(32, 1e-6) -> proj_in (1x1 conv = per-token
+    linear) -> LayerNorm 1 -> to_q | to_k | to_v (no bias), against torch fp32 on the bf16-rounded input."""
+    d = 320
+    g = torch.Generator().manual_seed(B * 100 + T)
+    r = lambda *s: torch.randn(*s, generator=g)
+    w = {'gn_g': 1 + 0.2 * r(d), 'gn_b': 0.2 * r(d), 'pi_w': r(d, d) / math.sqrt(d), 'pi_b': 0.1 * r(d), 'n1_g': 1 + 0.2 * r(d), 'n1_b': 0.2 * r(d),
+         'q_w': r(d, d) / math.sqrt(d), 'k_w': r(d, d) / math.sqrt(d), 'v_w': r(d, d) / math.sqrt(d)}
+    order = ['gn_g', 'gn_b', 'pi_w', 'pi_b', 'n1_g', 'n1_b', 'q_w', 'k_w', 'v_w']
+    dev = {k: w[k].to(DEV).float().contiguous() for k in order}
+    ld = d + pad
+    x = bf((r(B * T, ld) * (1 + 0.5 * r(1, ld)) + 0.3 * r(1, ld)))          # per-channel scale / offset: the group statistics matter
+    h0 = torch.full((B * T, d), float('nan'), device=DEV, dtype=torch.bfloat16)
+    qkv = torch.full((B * T, 3 * d), float('nan'), device=DEV, dtype=torch.bfloat16)
+    h = C.c_void_p()
+    mlib.check(L().mkd_tfm_head_create(d, *[P(dev[k]) for k in order], C.byref(h)), 'mkd_tfm_head_create')
+    try:
+        mlib.check(L().mkd_tfm_head_run(h, P(x), ld, 1e-6, P(h0), P(qkv), B, T, None), 'run')
+        sync()
+        first = (h0.clone(), qkv.clone())
+        mlib.check(L().mkd_tfm_head_run(h, P(x), ld, 1e-6, P(h0), P(qkv), B, T, None), 'run')
+        sync()
+    finally:
+        L().mkd_tfm_head_destroy(h)
+    assert torch.equal(first[0].view(torch.int16), h0.view(torch.int16)) and torch.equal(first[1].view(torch.int16), qkv.view(torch.int16))
+    xf = x[:, :d].float().cpu().view(B, T, d).permute(0, 2, 1)                    # [B, C, T]
+    gn = F.group_norm(xf, 32, w['gn_g'], w['gn_b'], 1e-6).permute(0, 2, 1).reshape(B * T, d)
+    h0_ref = gn @ w['pi_w'].T + w['pi_b']
+    ln = F.layer_norm(h0_ref, (d,), w['n1_g'], w['n1_b'], 1e-5)
+    qkv_ref = torch.cat([ln @ w['q_w'].T, ln @ w['k_w'].T, ln @ w['v_w'].T], 1)
+    r0, r1 = rel_l2(h0, h0_ref), rel_l2(qkv, qkv_ref)
+    print(f'tfm_head B={B} T={T}: h0 rel-L2 {r0:.3e}, qkv rel-L2 {r1:.3e}')
+    assert torch.isfinite(h0.float()).all() and torch.isfinite(qkv.float()).all()
+    assert r0 <= 4e-3 and r1 <= 8e-3
