@@ -411,6 +411,201 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const Pair<AttnIo> i
     }
 }
 
+
+// ---- long self-attention, d_head 40: K / V tiles by LDS-DMA ---------------------------------------------------------------------
+// The streaming kernel above spends 40 % of a wave's tile time between its MFMA / softmax phases: the tile's global loads land in
+// registers, are patched (zero padding, the ones columns) and stored to LDS between two barriers (profiles/exp_r4_attn_trace_after.txt:
+// barrier 419 | LDS stores 421 | barrier 214 | prefetch issue 415 of 3655 cycles per wave and 128-key tile).  Here the tile goes
+// global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write), into one of TWO buffers, one barrier per tile:
+//   K tile  [KT][40] bf16, rows of 80 B (5 chunks of 16 B; slot p of the tile = row p / 5, chunk p % 5)
+//   V tile  [KT][48] bf16, rows of 96 B (8 * odd dwords: conflict-free ds_read_b64_tr_b16); chunk 5 of every row comes from a constant
+//           16-byte block {1.0, 0 ...}: column 40 = the ones column that makes row 40 of O^T the softmax denominator (AttnCfg::ONES)
+// The padded K columns of the second k-step never exist in LDS: the Q fragment is zero beyond column 40 (so K may hold anything
+// finite there) except element 40 = -m_ref (AttnCfg::OFFS), which meets K column 40 = 1.0 - lanes of group g >= 1 read their second
+// K fragment from one constant 16-byte block in LDS instead of the tile.  Keys past the end of a partial last tile are CLAMPED to
+// the last valid row on the load side (finite values) and masked to -inf / p = 0 by the softmax, as above.
+// Numerics identical to attention_kernel<40, 8, KT, 2> (same MFMA order, same softmax): test_attention* compare both with torch.
+__device__ __attribute__((aligned(16))) const uint16_t g_attn_ones_chunk[8] = {0x3F80u, 0, 0, 0, 0, 0, 0, 0};
+
+template <int KT>
+struct AttnDmaCfg {
+    static constexpr int DH = 40, NW = 8, KROW = 80, VROW = 96;
+    static constexpr int KSLOTS = KT * 5, VSLOTS = KT * 6, SLOTS = KSLOTS + VSLOTS;      // 16-byte slots of one tile buffer
+    static constexpr int TILE_BYTES = SLOTS * 16;
+    static constexpr int ROUNDS = (SLOTS + 64 * NW - 1) / (64 * NW);                      // LDS-DMA instructions per thread and tile
+    static constexpr int ONES_OFF = 2 * TILE_BYTES;
+    static constexpr int LDS = ONES_OFF + 16;
+    static_assert(SLOTS % 64 == 0, "whole wave-instructions");
+};
+
+template <int KT>
+__global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo> io, int ldq, int ldk, int ldv, int ldo,
+                                                              int Tq, int Tk, int heads, float scale_log2e) {
+    using D = AttnDmaCfg<KT>;
+    using C = AttnCfg<40, KT, 2, 8>;
+    static_assert(C::OFFS && C::ONES && C::KS == 2 && C::MD == 3 && !C::TAIL, "the dh-40 reference-on-the-matrix-cores configuration");
+    constexpr int DH = 40, NW = 8, KB = KT / 16, NT = 64 * NW;
+    const bf16_t* __restrict__ const Q = io.g[blockIdx.z].q; const bf16_t* __restrict__ const K = io.g[blockIdx.z].k;
+    const bf16_t* __restrict__ const V = io.g[blockIdx.z].v; bf16_t* __restrict__ const O = io.g[blockIdx.z].o;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qc = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / heads, h = bh - b * heads;
+    const int q0 = blockIdx.x * (16 * NW) + w * 16;
+    const int qi = q0 + qc;
+
+    // staging geometry of this thread's slots (fixed per kernel): source row inside the tile, element offset, K or V, ones chunk
+    const bf16_t* kbase = K + (size_t)b * Tk * ldk + h * DH;
+    const bf16_t* vbase = V + (size_t)b * Tk * ldv + h * DH;
+    int srow[D::ROUNDS], scol[D::ROUNDS];
+    bool sv[D::ROUNDS], sone[D::ROUNDS];
+#pragma unroll
+    for (int i = 0; i < D::ROUNDS; ++i) {
+        const int p = i * NT + tid;
+        const bool isv = p >= D::KSLOTS;
+        const int pp = isv ? p - D::KSLOTS : p;
+        const int per = isv ? 6 : 5;
+        srow[i] = pp / per; scol[i] = (pp - srow[i] * per) * 8; sv[i] = isv; sone[i] = isv && scol[i] == 40;
+    }
+    auto issue = [&](int buf, int key0) {
+        char* dst = smem + buf * D::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < D::ROUNDS; ++i) {
+            if ((i * NT + w * 64) < D::SLOTS) {                      // wave-uniform: the last round is partial
+                int row = key0 + srow[i];
+                row = row < Tk ? row : Tk - 1;
+                const bf16_t* src = sv[i] ? vbase + (size_t)row * ldv + scol[i] : kbase + (size_t)row * ldk + scol[i];
+                unsigned long long sa = sone[i] ? (unsigned long long)g_attn_ones_chunk : (unsigned long long)src;
+                asm volatile("" : "+v"(sa));                      // (one load per call site)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                                 (__attribute__((address_space(3))) void*)(dst + (i * NT + w * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    const int ntiles = (Tk + KT - 1) / KT;
+    issue(0, 0);
+    if (tid == 0) *(uint4*)(smem + D::ONES_OFF) = make_uint4(0x3F80u, 0u, 0u, 0u);
+
+    // Q fragments (B operand of S^T = K Q^T), pre-scaled by scale * log2(e): the MFMAs deliver scores in the log2 domain
+    bf16x8 qf[2];
+    {
+        const bf16_t* qrow = Q + ((size_t)b * Tq + (qi < Tq ? qi : 0)) * ldq + h * DH;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            U16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.v[j] = 0;
+            if (qi < Tq && 32 * s + 8 * g < DH) t = *(const U16x8*)(qrow + 32 * s + 8 * g);
+            qf[s] = __builtin_bit_cast(bf16x8, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)((float)qf[s][j] * scale_log2e);
+        }
+    }
+    f32x4 oacc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_ref = 0.f;
+    const int k1s = g == 0 ? 16 * D::KROW : 0;          // second K fragment: the tile's chunk 4 (g = 0) or the constant ones block
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's part of tile t has landed
+        __syncthreads();                                       // ... and everyone's; tile t - 1 is consumed: its buffer is free
+        if (t + 1 < ntiles) issue((t + 1) & 1, key0 + KT);
+        const char* ks = smem + (t & 1) * D::TILE_BYTES;
+        const char* vs = ks + D::KSLOTS * 16;
+
+        f32x4 st[KB];
+        {
+            const char* k0p = ks + qc * D::KROW + g * 16;
+            const char* k1p = g == 0 ? ks + qc * D::KROW + 64 : smem + D::ONES_OFF;
+#pragma unroll
+            for (int mf = 0; mf < KB; ++mf) {
+                st[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x8 kf0 = *(const bf16x8*)(k0p + mf * 16 * D::KROW);
+                const bf16x8 kf1 = *(const bf16x8*)(k1p + mf * k1s);
+                st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[0], st[mf], 0, 0, 0);
+                st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1], st[mf], 0, 0, 0);
+            }
+        }
+        // st = s c - m_ref (see attention_kernel, AttnCfg::OFFS)
+        {
+            float mx = -INFINITY;
+            if (key0 + KT > Tk) {
+#pragma unroll
+                for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = (key0 + 16 * mf + 4 * g + r < Tk) ? st[mf][r] : -INFINITY;
+                        st[mf][r] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+            } else {
+#pragma unroll
+                for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[mf][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const bool need = t == 0 || mx > C::OFFS_THRESH;
+            if (__any(need)) {
+                const float m_new = need ? (float)(__bf16)(m_ref + mx) : m_ref;
+                const float delta = m_new - m_ref;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref = m_new;
+#pragma unroll
+                for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[mf][r] -= delta;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) oacc[i] *= alpha;
+                if (g == 1) qf[1][0] = (__bf16)(-m_ref);
+            }
+#pragma unroll
+            for (int mf = 0; mf < KB; ++mf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[mf][r] = __builtin_amdgcn_exp2f(st[mf][r]);
+        }
+        // O^T[d][q] += V^T[d][key'] P^T[key'][q] (attention_kernel's operand order)
+#pragma unroll
+        for (int s = 0; s < KT / 32; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (__bf16)st[2 * s][j];
+                pf[4 + j] = (__bf16)st[2 * s + 1][j];
+            }
+            const char* vblk = vs + (32 * s + 4 * g + (qc >> 2)) * D::VROW + (qc & 3) * 8;
+#pragma unroll
+            for (int md = 0; md < 3; ++md) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + md * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + 16 * D::VROW + md * 32));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[md], 0, 0, 0);
+            }
+        }
+    }
+    const float l_run = __shfl(oacc[2][0], 32 + qc, 64);        // row 40 of O^T: fragment 2, lane group 2, register 0
+    const float inv = 1.0f / l_run;
+    if (qi < Tq) {
+        bf16_t* orow = O + ((size_t)b * Tq + qi) * ldo + h * DH;
+#pragma unroll
+        for (int md = 0; md < 3; ++md) {
+            const int d = 16 * md + 4 * g;
+            if (d < DH) {
+                U16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.v[r] = f32_to_bf16(oacc[md][r] * inv);
+                *(U16x4*)(orow + d) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int attn_set_trace(long long* buf) {
@@ -471,6 +666,13 @@ int launch_attention(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const b
         else if (one96) MKD_ATTN_LAUNCH(D, 4, 96, 0);                                                         \
         else MKD_ATTN_LAUNCH(D, 4, 64, 0);                                                                    \
         break;
+    static const bool dma40 = !(getenv("MKD_ATTN_DMA") && atoi(getenv("MKD_ATTN_DMA")) == 0);      // (A/B knob)
+    if (wide && msum == 2 && dh == 40 && dma40) {          // K / V tiles by LDS-DMA, two buffers, one barrier per tile
+        using D = AttnDmaCfg<MKD_ATTN_KT_WIDE>;
+        hipLaunchKernelGGL((attention_dma40_kernel<MKD_ATTN_KT_WIDE>), grid, dim3(512), D::LDS, stream, io, ldq, ldk, ldv, ldo, Tq, Tk, heads, sl);
+        MKD_LAUNCH_CHECK("attention_dma40_kernel");
+        return 0;
+    }
     switch (dh) {
         MKD_ATTN_CASE(8)
         MKD_ATTN_CASE(16)

@@ -292,7 +292,8 @@ def test_layernorm(rows, d):
 
 @pytest.mark.parametrize('B,Tq,Tk,heads,dh', [(2, 256, 256, 8, 40), (1, 1024, 1024, 2, 40), (2, 64, 64, 8, 160), (2, 16, 16, 8, 160),
                                             (2, 256, 77, 8, 80), (2, 100, 77, 4, 40), (1, 64, 77, 2, 32), (2, 16, 77, 8, 160),
-                                            (1, 200, 130, 3, 64), (2, 1024, 77, 8, 40), (1, 64, 96, 2, 80), (1, 48, 65, 2, 160), (1, 64, 64, 2, 80)])
+                                            (1, 200, 130, 3, 64), (2, 1024, 77, 8, 40), (1, 64, 96, 2, 80), (1, 48, 65, 2, 160), (1, 64, 64, 2, 80),
+                                            (1, 1100, 1100, 2, 40), (1, 1024, 1153, 1, 40)])      # (ragged queries / a 1-key last tile in the LDS-DMA kernel)
 def test_attention(B, Tq, Tk, heads, dh):
     lib = L()
     g = torch.Generator().manual_seed(Tq + Tk + dh)
