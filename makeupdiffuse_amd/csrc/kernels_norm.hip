@@ -315,99 +315,6 @@ struct SlabGn {
     bf16_t* raw; int ldraw;
 };
 
-// The same single launch on FINER channel chunks: EV = 4 or 2 channels per vector (8- / 4-byte loads) instead of 8.  The chunk of a
-// workgroup must be whole groups AND whole vectors: with 16-byte vectors C = 320 (10 channels per group) gives 40-channel chunks,
-// 8 per sample - 64 workgroups at batch 8, and a CU pulls the slab (always L2 misses: another kernel wrote it) at 16-28 GB/s
-// whatever it does (5.1 of 10.9 us).  With 4-channel vectors the chunk is 20 channels (128 workgroups), with 2-channel
-// vectors one group (256): the same bytes through two / four times as many CUs.  Register statistics as above (cg >= EV: a vector
-// touches at most two groups), two barriers, fixed summation order.
-template <int EV> struct alignas(EV * 2) GnVec { uint16_t v[EV]; };
-template <int NV, int EV>
-__global__ __launch_bounds__(NV >= 32 ? 512 : 1024) void gn_fine_kernel(const Pair<NormIo> io, int ld_in, int ld_out, float eps, int silu, int hw, int C, int groups, int gpb) {
-    extern __shared__ __attribute__((aligned(16))) float s_red[];    // [waves][gpb][2], then [gpb][2] mean / rstd
-    const bf16_t* __restrict__ const x = io.g[blockIdx.z].x; bf16_t* __restrict__ const y = io.g[blockIdx.z].y;
-    const float* __restrict__ const gamma = io.g[blockIdx.z].gamma; const float* __restrict__ const beta = io.g[blockIdx.z].beta;
-    const int cg = C / groups;
-    const int nch = gpb * cg;                 // channels of this block (multiple of EV)
-    const int V = nch / EV;
-    const int NT = blockDim.x;
-    const int P = NT / V;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int c0 = blockIdx.x * nch;
-    const bool active = tid < V * P;
-    const int v = active ? tid % V : 0;
-    const int pl = active ? tid / V : 0;
-    const bf16_t* xin = x + (size_t)b * hw * ld_in + c0 + v * EV;
-    GnVec<EV> keep[NV];
-    float pg[EV], pb[EV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {            // unconditional, clamped (see gn_fused_kernel); inactive threads re-read vector 0
-        const int r = pl + i * P;
-        keep[i] = *(const GnVec<EV>*)(xin + (size_t)(r < hw ? r : hw - 1) * ld_in);
-    }
-#pragma unroll
-    for (int j = 0; j < EV; ++j) { pg[j] = gamma[c0 + v * EV + j]; pb[j] = beta[c0 + v * EV + j]; }
-    const int gA = (v * EV) / cg;
-    const int split = min(EV, (gA + 1) * cg - v * EV);          // channels [0, split) belong to group gA, the rest to gA + 1
-    float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int r = pl + i * P;
-        if (active && r < hw) {
-#pragma unroll
-            for (int j = 0; j < EV; ++j) {
-                const float f = bf16_to_f32(keep[i].v[j]);
-                if (j < split) { a0 += f; q0 += f * f; } else { a1 += f; q1 += f * f; }
-            }
-        }
-    }
-    const int nw = NT >> 6, wv = tid >> 6;
-    float* gstat = s_red + nw * gpb * 2;
-    for (int g = 0; g < gpb; ++g) {
-        float sg = (gA == g ? a0 : 0.f) + (gA + 1 == g ? a1 : 0.f);
-        float qg = (gA == g ? q0 : 0.f) + (gA + 1 == g ? q1 : 0.f);
-        sg = wave_sum(sg); qg = wave_sum(qg);
-        if ((tid & 63) == 0) { s_red[(wv * gpb + g) * 2] = sg; s_red[(wv * gpb + g) * 2 + 1] = qg; }
-    }
-    __syncthreads();
-    if (tid < gpb) {
-        float a = 0.f, q = 0.f;
-        for (int k = 0; k < nw; ++k) { a += s_red[(k * gpb + tid) * 2]; q += s_red[(k * gpb + tid) * 2 + 1]; }
-        const float n = (float)hw * (float)cg;
-        const float mean = a / n;
-        float var = q / n - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        gstat[tid * 2] = mean;
-        gstat[tid * 2 + 1] = rsqrtf(var + eps);
-    }
-    __syncthreads();
-    if (!active) return;
-    float sa[EV], sb[EV];
-#pragma unroll
-    for (int j = 0; j < EV; ++j) {
-        const int g = j < split ? gA : gA + 1;
-        const float a = pg[j] * gstat[g * 2 + 1];
-        sa[j] = a;
-        sb[j] = pb[j] - gstat[g * 2] * a;
-    }
-    bf16_t* yout = y + (size_t)b * hw * ld_out + c0 + v * EV;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int r = pl + i * P;
-        if (r < hw) {
-            GnVec<EV> o;
-#pragma unroll
-            for (int j = 0; j < EV; ++j) {
-                float f = bf16_to_f32(keep[i].v[j]) * sa[j] + sb[j];
-                if (silu) f = silu_f(f);
-                o.v[j] = f32_to_bf16(f);
-            }
-            *(GnVec<EV>*)(yout + (size_t)r * ld_out) = o;
-        }
-    }
-}
-
 template <int NV>
 __global__ __launch_bounds__(512) void gn_slab_kernel(const Pair<SlabGn> ag, const Pair<NormIo> io, int ld_out,
                                                                        float eps, int silu, int hw, int C, int groups, int gpb) {
@@ -798,38 +705,6 @@ int launch_groupnorm(const bf16_t* x, int ld_in, const float* gamma, const float
                 else if (per_of(512) <= 16) { nt = 512; per = per_of(512); }
                 else if (per_of(1024) <= 8) { nt = 1024; per = per_of(1024); }
                 else { nt = 256; per = 1 << 20; }
-                // too few workgroups to pull the slab at more than a fraction of the chip's rate: finer channel chunks (gn_fine_kernel).
-                // 4-channel vectors when they already give >= 160 workgroups, else 2-channel ones if those give more
-                static const int fine = getenv("MKD_GN_FINE") ? atoi(getenv("MKD_GN_FINE")) : 1;      // (A/B knob)
-                const int gz = second ? 2 : 1;
-                if (fine && (groups / gpb) * batch * gz < 160) {
-                    int best_ev = 0, best_gf = 0, best_nt = 0, best_per = 0, best_wgs = (groups / gpb) * batch * gz;
-                    for (int ev = 4; ev >= 2; ev >>= 1) {
-                        if (cg < ev) continue;
-                        int gf = 1;
-                        while (gf <= groups && ((gf * cg) % ev || groups % gf)) ++gf;
-                        if (gf > groups) continue;
-                        const int Vf = gf * cg / ev, wgs = (groups / gf) * batch * gz;
-                        if (wgs <= best_wgs) continue;
-                        int ntf = 0, perf = 0;
-                        for (int t = 256; t <= 1024 && !ntf; t <<= 1) { const int Pf = t / Vf; if (Pf >= 1 && (hw + Pf - 1) / Pf <= (t <= 512 ? 32 : 16)) { ntf = t; perf = (hw + Pf - 1) / Pf; } }      // (32 vectors per thread: 512-thread register budget)
-                        if (!ntf) continue;
-                        best_ev = ev; best_gf = gf; best_nt = ntf; best_per = perf; best_wgs = wgs;
-                        if (wgs >= 160) break;
-                    }
-                    if (best_ev) {
-                        const int gf = best_gf, ntf = best_nt, perf = best_per;
-                        const size_t ldsf = (size_t)((ntf >> 6) * gf * 2 + 2 * gf) * sizeof(float);
-                        dim3 gridf(groups / gf, batch, gz);
-#define MKD_GNF_LAUNCH(NVV, EVV) hipLaunchKernelGGL((gn_fine_kernel<NVV, EVV>), gridf, dim3(ntf), ldsf, stream, io, ld_in, ld_out, eps, silu, hw, C, groups, gf)
-#define MKD_GNF_EV(EVV) do { if (perf <= 4) MKD_GNF_LAUNCH(4, EVV); else if (perf <= 8) MKD_GNF_LAUNCH(8, EVV); else if (perf <= 16) MKD_GNF_LAUNCH(16, EVV); else MKD_GNF_LAUNCH(32, EVV); } while (0)
-                        if (best_ev == 4) MKD_GNF_EV(4); else MKD_GNF_EV(2);
-#undef MKD_GNF_EV
-#undef MKD_GNF_LAUNCH
-                        MKD_LAUNCH_CHECK("gn_fine_kernel");
-                        return 0;
-                    }
-                }
                 const size_t lds = (size_t)(2 * nt * 8 + 2 * nch + 2 * gpb) * sizeof(float);
                 dim3 grid(groups / gpb, batch, second ? 2 : 1);
 #define MKD_GN_LAUNCH(NVV)                                                                                              \
