@@ -87,7 +87,6 @@ struct TfmTailArgs {
     bf16_t* out; int ldo;
     int T;                      // tokens per sample (multiple of TFM_TM)
     int Tk;                     // context keys (<= 16 * TFM_KF)
-    int nwg;                    // workgroups that own a token tile; blocks nwg .. gridDim.x - 1 only warm their XCD's L2 (tfm_prologue)
     float scale_log2e;          // dh^-0.5 * log2(e)
     long long* trace;           // MKD_TFM_TRACE builds only: [workgroup][wave][32] wall_clock64 stamps (tools/exp_r4_tfm_trace.py)
 };
@@ -233,16 +232,11 @@ __device__ __forceinline__ void tfm_prologue(const TfmTailArgs& a, char* smem, c
     // the stream: workgroup i of the XCD (workgroups are dealt round-robin, blockIdx / 8 numbers them - a speed assumption only)
     // touches granule i, i + n, ... once at kernel start (one dword per 64 B, landing in an LDS pad nobody reads).  The same for
     // what this workgroup reads late and only once: its h0 / x_in residual tiles.
-    // When the token tiles leave CUs idle (fewer than 256 workgroups), the launch adds WARMER workgroups on them that do nothing but
-    // this (tfm_tail_kernel): the tile workgroups then wait for their own operands only, not for their share of the HBM fetch
-    // (a CU pulls misses at ~24 GB/s: 3.3 MB over the 16 workgroups of an XCD held every first barrier for ~9 us).
     {
         char* pad = smem + C::PF_OFF + w * 256;
-        if ((int)gridDim.x == a.nwg) {
-            const int nsl = min(16, max(1, a.nwg >> 3)), sl = ((int)blockIdx.x >> 3) % nsl;
-            const char* base = (const char*)a.wpk + lane * 64;
-            for (int gi = sl + nsl * w; gi < C::UNITS / 4; gi += nsl * TFM_NW) warm64(base + (size_t)gi * 4096, pad);
-        }
+        const int nsl = min(16, max(1, (int)gridDim.x >> 3)), sl = ((int)blockIdx.x >> 3) % nsl;
+        const char* base = (const char*)a.wpk + lane * 64;
+        for (int gi = sl + nsl * w; gi < C::UNITS / 4; gi += nsl * TFM_NW) warm64(base + (size_t)gi * 4096, pad);
         constexpr int SEG = D * 2 / 64;                          // 64-byte segments per tile row
         for (int i = lane; i < (TFM_TM / TFM_NW) * SEG; i += 64) {
             const int rr = (TFM_TM / TFM_NW) * w + i / SEG, sg = i - (i / SEG) * SEG;
@@ -542,14 +536,6 @@ __global__ __launch_bounds__(64 * TFM_NW) void tfm_tail_kernel(const TfmTailArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keeps every per-wave offset in SGPRs
-    if ((int)blockIdx.x >= a.nwg) {          // warmer: this XCD's share of the weight stream -> L2, in stream order, and out
-        const int nwarm = ((int)gridDim.x - a.nwg) >> 3, j = ((int)blockIdx.x - a.nwg) >> 3;      // (workgroups are dealt to the XCDs round-robin)
-        const char* base = (const char*)a.wpk + lane * 64;
-        char* pad = smem + w * 256;
-        for (int gi = j * TFM_NW + w; gi < C::UNITS / 4; gi += nwarm * TFM_NW) warm64(base + (size_t)gi * 4096, pad);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
     if (C::NWA == TFM_NW || w < C::NWA) tfm_wave<D, C::NFA>(a, smem, w, lane, w * C::NFA);
     else tfm_wave<D, C::NFB>(a, smem, w, lane, C::NWA * C::NFA + (w - C::NWA) * C::NFB);
 }
@@ -896,11 +882,7 @@ int launch_tfm_tail(int d, const bf16_t* wpk, const float* vec, const bf16_t* a1
         if (e != hipSuccess) return mkd_fail(-2, std::string("hipFuncSetAttribute(tfm_tail LDS): ") + hipGetErrorString(e));
         attr = true;
     }
-    a.nwg = M / TFM_TM;
-    static const int warmers = getenv("MKD_TFM_WARMERS") ? atoi(getenv("MKD_TFM_WARMERS")) : 1;      // (A/B knob)
-    int grid = a.nwg;
-    if (warmers && a.nwg % 8 == 0 && a.nwg <= 192) grid = 256;          // idle CUs pull the weights (8 per XCD at least)
-    hipLaunchKernelGGL(tfm_tail_kernel<320>, dim3(grid), dim3(64 * TFM_NW), C::LDS, stream, a);
+    hipLaunchKernelGGL(tfm_tail_kernel<320>, dim3(M / TFM_TM), dim3(64 * TFM_NW), C::LDS, stream, a);
     MKD_LAUNCH_CHECK("tfm_tail_kernel");
     return 0;
 }
