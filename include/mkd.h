@@ -140,6 +140,16 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
                const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
                float cfg_scale, float* x_out, int use_graph, void* stream);
 
+/* The same loop with eta > 0 (cddim.py:56-78 / UPSTREAM DDIMSampler.p_sample_ddim: dir_xt = sqrt(1 - a_prev - sigma_t^2) e_t,
+ * x_prev += sigma_t * noise * temperature).  sigmas: host array like the other tables (ddim_sigmas[index]); noise: DEVICE array
+ * [n_steps][B*4*h*w] fp32, row k = the draw of the k-th executed step (the caller draws them in loop order, as the reference's
+ * noise_like does step by step); both NULL, or every sigma 0: mkd_sample.  The graph replays unchanged (the step reads its
+ * sigma / noise row from the device-resident step state). */
+int mkd_sample_eta(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps,
+                   const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
+                   const float* sigmas, const float* noise, float temperature,
+                   float cfg_scale, float* x_out, int use_graph, void* stream);
+
 /* ---- first-stage decoder ------------------------------------------------ */
 /* yaml first_stage_config.params.ddconfig (diffmodels/base_diffusion_makeup.yaml:86-107), decoder half only. */
 typedef struct mkd_vae_config {

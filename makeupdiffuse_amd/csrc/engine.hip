@@ -1830,14 +1830,22 @@ struct mkd_ctx {
     }
 
     int sample(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
-               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
-        const int rc = sample_impl(x_T, batch, n_steps, timesteps, alphas, alphas_prev, s1m, cfg_scale, x_out, use_graph, stream);
+               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream,
+               const float* sigmas = nullptr, const float* noise = nullptr, float temperature = 1.0f) {
+        const int rc = sample_impl(x_T, batch, n_steps, timesteps, alphas, alphas_prev, s1m, cfg_scale, x_out, use_graph, stream, sigmas, noise, temperature);
         temb_skip = false;          // (a later mkd_eps runs its own time-embedding chain)
         return rc;
     }
     int sample_impl(const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
-               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream) {
+               const float* alphas_prev, const float* s1m, float cfg_scale, float* x_out, int use_graph, hipStream_t stream,
+               const float* sigmas, const float* noise, float temperature) {
         if (!prepared) return mkd_fail(MKD_ERR_STATE, "mkd_sample before mkd_prepare");
+        bool stochastic = false;
+        if (sigmas) for (int i = 0; i < n_steps; ++i) {
+            if (!(sigmas[i] >= 0.f) || 1.0f - alphas_prev[i] - sigmas[i] * sigmas[i] < 0.f) return mkd_fail(MKD_ERR_ARG, "mkd_sample_eta: sigma out of range");
+            stochastic = stochastic || sigmas[i] != 0.f;
+        }
+        if (stochastic && !noise) return mkd_fail(MKD_ERR_ARG, "mkd_sample_eta: sigma > 0 needs the noise draws");
         const bool cfg_on = cfg_scale != 1.0f;
         if (cfg_on ? (B != 2 * batch) : (B != batch))
             return mkd_fail(MKD_ERR_ARG, "mkd_sample: prepared batch must be B (cfg_scale == 1) or 2B (uncond first)");
@@ -1863,9 +1871,13 @@ struct mkd_ctx {
                 h_state->timesteps[i] = timesteps[i];
                 h_state->coef[4 * i + 0] = 1.0f / sqrtf(alphas[i]);
                 h_state->coef[4 * i + 1] = sqrtf(alphas_prev[i]);
-                h_state->coef[4 * i + 2] = sqrtf(1.0f - alphas_prev[i]);
+                const float sg = stochastic ? sigmas[i] : 0.f;
+                h_state->coef[4 * i + 2] = sqrtf(1.0f - alphas_prev[i] - sg * sg);
                 h_state->coef[4 * i + 3] = s1m[i];
+                h_state->sigma[i] = sg;
             }
+            h_state->noise = stochastic ? noise : nullptr; h_state->temperature = temperature; h_state->n_steps = n_steps;
+            h_state->cur_sigma = 0.f; h_state->cur_row = 0;
             MKD_HIP_CHECK(hipEventRecord(ev_loop_in, stream));
             MKD_HIP_CHECK(hipStreamWaitEvent(loop_stream, ev_loop_in, 0));
             MKD_HIP_CHECK(hipMemcpyAsync(s_state, h_state, sizeof(StepState), hipMemcpyHostToDevice, loop_stream));
@@ -1951,8 +1963,9 @@ struct mkd_ctx {
                 rc = eps(xa, s_t, s_eps, stream); if (rc) return rc;
                 ec = s_eps;
             }
-            rc = launch_ddim_step(xa, ec, eu, cfg_scale, alphas[index], alphas_prev[index], 0.f, s1m[index], nullptr, 1.f,
-                                  xb, nullptr, n, stream);
+            const float sg = stochastic ? sigmas[index] : 0.f;
+            rc = launch_ddim_step(xa, ec, eu, cfg_scale, alphas[index], alphas_prev[index], sg, s1m[index], sg != 0.f ? noise + (int64_t)i * n : nullptr,
+                                  temperature, xb, nullptr, n, stream);
             if (rc) return rc;
             float* tmp = xa; xa = xb; xb = tmp;
         }
@@ -2464,6 +2477,13 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
     if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
     return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
                        (hipStream_t)stream);
+}
+int mkd_sample_eta(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps, const float* alphas,
+                   const float* alphas_prev, const float* sqrt_one_minus_alphas, const float* sigmas, const float* noise, float temperature,
+                   float cfg_scale, float* x_out, int use_graph, void* stream) {
+    if (!ctx) return mkd_fail(MKD_ERR_ARG, "null ctx");
+    return ctx->sample(x_T, batch, n_steps, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas, cfg_scale, x_out, use_graph,
+                       (hipStream_t)stream, sigmas, noise, temperature);
 }
 // The tile tuner's state (forced tile, XCD mode, per-shape overrides) is PROCESS-global by design: it belongs to the single-kernel
 // entries and to the tuners.  A change bumps the global plan epoch, so EVERY live context re-plans at its next mkd_prepare and a plan

@@ -47,6 +47,7 @@ __global__ void step_setup_kernel(StepState* st, int64_t* t_out, int batch, cons
         if (threadIdx.x == 0) {
             st->cur[0] = st->coef[4 * i + 0]; st->cur[1] = st->coef[4 * i + 1];
             st->cur[2] = st->coef[4 * i + 2]; st->cur[3] = st->coef[4 * i + 3];
+            st->cur_sigma = st->sigma[i]; st->cur_row = st->n_steps - 1 - i;
         }
     }
     temb_copy_rows(ts, i, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
@@ -60,13 +61,17 @@ __global__ void temb_select_kernel(const TembSel ts, int step) {
 __global__ void ddim_step_state_kernel(float* __restrict__ x, const float* __restrict__ eps_c, const float* __restrict__ eps_u,
                                        float cfg_scale, StepState* __restrict__ st, int64_t n) {
     const float sqrt_at_inv = st->cur[0], sqrt_aprev = st->cur[1], dir_coef = st->cur[2], s1m = st->cur[3];
+    const float* __restrict__ const nz = (st->noise && st->cur_sigma != 0.f) ? st->noise + (int64_t)st->cur_row * n : nullptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->counter = st->counter - 1;      // (nothing else in this kernel reads it)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float e = eps_c[i];
         if (eps_u) { const float u = eps_u[i]; e = u + cfg_scale * (e - u); }
         const float p0 = (x[i] - s1m * e) * sqrt_at_inv;
-        x[i] = sqrt_aprev * p0 + dir_coef * e;
+        float xp = sqrt_aprev * p0 + dir_coef * e;
+        if (nz) xp += st->cur_sigma * nz[i] * st->temperature;          // (ddim_step_kernel's order of operations: same bits as the eager loop)
+        x[i] = xp;
     }
+
 }
 
 // ---- GEGLU: y = a * gelu_erf(gate) ----------------------------------------------------------------

@@ -122,6 +122,11 @@ struct StepState {
     float cur[4];                          // sqrt(1/a_t), sqrt(a_prev), sqrt(1-a_prev), sqrt(1-a_t) of the current step
     int64_t timesteps[MKD_MAX_STEPS];
     float coef[4 * MKD_MAX_STEPS];
+    // eta > 0 (cddim.py:74-78): x_prev += sigma_t * noise * temperature.  noise: [n_steps][n] fp32 on the device, row k = the draw of the
+    // k-th EXECUTED step (index n_steps - 1 - k); null: deterministic loop.  cur_sigma / cur_row: this step's, set by step_setup_kernel
+    float sigma[MKD_MAX_STEPS];
+    const float* noise; float temperature; int n_steps;
+    float cur_sigma; int cur_row;
 };
 
 // Time embedding of a sampling call: row `step` of tab[k] ([steps, n[k]] fp32, one table per net) is copied into every one of

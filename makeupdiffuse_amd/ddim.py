@@ -97,11 +97,26 @@ class DDIMSampler:
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         fast = getattr(self.model, 'sample_loop_fast', None)
-        if fast is not None and callback is None and noise_dropout == 0.0 and float(self.ddim_sigmas.abs().max()) == 0.0:
-            # eta == 0: the whole loop runs inside libmkd (mkd_sample); no per-step host work
+        if fast is not None and callback is None:
+            # the whole loop runs inside libmkd (mkd_sample / mkd_sample_eta); no per-step host work.  eta > 0: the draws of the
+            # stochastic branch (cddim.py:74-78) are taken here, one per step with sigma_t != 0 in loop order - the generator is
+            # consumed exactly as by the step-by-step loop below - and handed over as one [steps, ...] tensor
+            sig = self.ddim_sigmas[:total_steps]
+            kw = {}
+            if float(sig.abs().max()) != 0.0:
+                draws = []
+                for i in range(total_steps):
+                    if float(sig[total_steps - i - 1]) != 0.0:
+                        nz = noise_like(tuple(shape), device, False)
+                        if noise_dropout > 0.0:
+                            nz = torch.nn.functional.dropout(nz, p=noise_dropout)
+                    else:
+                        nz = torch.zeros(tuple(shape), device=device)
+                    draws.append(nz)
+                kw = dict(sigmas=sig, noise=torch.stack(draws), temperature=temperature)
             img = fast(img, cond, timesteps, self.ddim_alphas[:total_steps], self.ddim_alphas_prev[:total_steps],
                        self.ddim_sqrt_one_minus_alphas[:total_steps], unconditional_guidance_scale,
-                       unconditional_conditioning)
+                       unconditional_conditioning, **kw)
             intermediates['x_inter'].append(img)
             return img, intermediates
         for i, step in enumerate(time_range):

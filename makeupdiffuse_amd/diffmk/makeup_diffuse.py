@@ -258,14 +258,18 @@ class BaseMakeUpDiffuse:
     def ddim_step(self, x, e_c, e_u, scale, a_t, a_prev, sigma_t, s1m_t, noise, temperature):
         return self._require_engine().ddim_step(x, e_c, e_u, scale, a_t, a_prev, sigma_t, s1m_t, noise, temperature)
 
+    # hipGraph replay of the sampling loop (one captured step, five steps per graph): the configuration bench.py measures.  False: eager
+    sample_use_graph = True
+
     def sample_loop_fast(self, x_latent, cond, timesteps, alphas, alphas_prev, sqrt_one_minus_alphas,
-                         unconditional_guidance_scale=1.0, unconditional_conditioning=None):
+                         unconditional_guidance_scale=1.0, unconditional_conditioning=None, sigmas=None, noise=None, temperature=1.0):
         cfg_on = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
         c = self.cfg_conditioning(unconditional_conditioning, cond) if cfg_on else cond
         eng = self._bind_cond(c, x_latent.shape[2:])
         return eng.sample(x_latent, [int(v) for v in timesteps], [float(v) for v in alphas], [float(v) for v in alphas_prev],
                           [float(v) for v in sqrt_one_minus_alphas],
-                          cfg_scale=float(unconditional_guidance_scale) if cfg_on else 1.0)
+                          cfg_scale=float(unconditional_guidance_scale) if cfg_on else 1.0, use_graph=bool(self.sample_use_graph),
+                          sigmas=None if sigmas is None else [float(v) for v in sigmas], noise=noise, temperature=float(temperature))
 
     # ---- sampling drivers ----------------------------------------------------------------------------------------
     @torch.no_grad()

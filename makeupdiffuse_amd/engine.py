@@ -384,8 +384,10 @@ class MkdEngine:
         return x_prev, x0
 
     def sample(self, x_T: torch.Tensor, timesteps: Sequence[int], alphas: Sequence[float], alphas_prev: Sequence[float],
-               sqrt_one_minus_alphas: Sequence[float], cfg_scale: float = 1.0, use_graph: bool = False) -> torch.Tensor:
-        """Whole eta=0 reverse loop in one call (cddim.py:81-100). Prepared batch must be B or 2B (CFG)."""
+               sqrt_one_minus_alphas: Sequence[float], cfg_scale: float = 1.0, use_graph: bool = False,
+               sigmas: Optional[Sequence[float]] = None, noise: Optional[torch.Tensor] = None, temperature: float = 1.0) -> torch.Tensor:
+        """Whole reverse loop in one call (cddim.py:81-100). Prepared batch must be B or 2B (CFG).  eta > 0 (cddim.py:74-78):
+        ``sigmas`` like the other tables and ``noise`` [n_steps, B, 4, h, w], row k = the draw of the k-th executed step."""
         x_T = _f32c(x_T, self.device)
         cfg_on = float(cfg_scale) != 1.0
         want_b = self.batch // 2 if cfg_on else self.batch
@@ -403,6 +405,20 @@ class MkdEngine:
         ap = (C.c_float * n)(*[float(v) for v in alphas_prev])
         s1 = (C.c_float * n)(*[float(v) for v in sqrt_one_minus_alphas])
         out = torch.empty_like(x_T)
+        if sigmas is not None and any(float(v) != 0.0 for v in sigmas):
+            if len(sigmas) != n:
+                raise ValueError('sigmas must be as long as timesteps')
+            if noise is None or tuple(noise.shape) != (n, *x_T.shape):
+                raise ValueError(f'eta > 0 needs noise of shape {(n, *x_T.shape)} (one draw per executed step)')
+            noise = _f32c(noise, self.device)
+            sg = (C.c_float * n)(*[float(v) for v in sigmas])
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.mkd_sample_eta(self._ctx, C.c_void_p(x_T.data_ptr()), x_T.shape[0], n, ts, a, ap, s1, sg,
+                                                   C.c_void_p(noise.data_ptr()), float(temperature), float(cfg_scale),
+                                                   C.c_void_p(out.data_ptr()), int(use_graph), C.c_void_p(_stream())), 'mkd_sample_eta')
+                if use_graph:
+                    torch.cuda.synchronize(self.device)          # the replayed loop reads `noise` after this call returns: keep it alive
+            return out
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mkd_sample(self._ctx, C.c_void_p(x_T.data_ptr()), x_T.shape[0], n, ts, a, ap, s1,
                                            float(cfg_scale), C.c_void_p(out.data_ptr()), int(use_graph),

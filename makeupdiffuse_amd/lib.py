@@ -64,6 +64,7 @@ SIGNATURES = {
     'mkd_eps': (_I, [_P, _P, _P, _P, _P]),
     'mkd_ddim_step': (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _P, _F, _P, _P, _L, _P]),
     'mkd_sample': (_I, [_P, _P, _I, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _F, _P, _I, _P]),
+    'mkd_sample_eta': (_I, [_P, _P, _I, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P, _F, _F, _P, _I, _P]),
     'mkd_vae_configure': (_I, [_P, C.POINTER(VaeConfigC)]),
     'mkd_vae_finalize': (_I, [_P]),
     'mkd_decode': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),

@@ -125,8 +125,9 @@ def test_mkddim_sampler_on_device_vs_golden(model, G):
 
 def test_ddim_sampler_eta_positive_on_device_vs_oracle(model, G, weights, monkeypatch):
     """the stochastic branch of the step (reference diffmk/cddim.py:74-78: x_prev += sigma_t * randn * temperature)
-    through the CLASS on the device - DDIMSampler.sample(eta = 0.5), which leaves the in-library loop for the per-step path - with the
-    noise draws injected, against oracle.sampler.denoising_step(noise=...) driven by the same draws; with and without guidance."""
+    through the CLASS on the device - DDIMSampler.sample(eta = 0.5): the draws are taken in loop order and the whole loop runs inside
+    the library (mkd_sample_eta, graph replay; round 4) - with the noise draws injected, against oracle.sampler.denoising_step(noise=...)
+    driven by the same draws; with and without guidance.  Graph replay == the eager in-library loop == the per-step host loop."""
     import makeupdiffuse_amd.ddim as ddim_mod
     from makeupdiffuse_amd.ddim import DDIMSampler
     ocfg, sd, _, _ = weights
@@ -157,6 +158,20 @@ def test_ddim_sampler_eta_positive_on_device_vs_oracle(model, G, weights, monkey
                             unconditional_guidance_scale=scale, unconditional_conditioning=ucond)
         assert used == list(range(S))                      # one draw per step: the stochastic branch ran every step
         check(out, ref, lim[0], lim[1], f'DDIMSampler.sample(eta=0.5, temperature=0.8, scale={scale})')
+        del used[:]
+        model.sample_use_graph = False                     # the eager in-library loop: same kernels, same bits
+        try:
+            out_e, _ = smp.sample(S, x.shape[0], tuple(x.shape[1:]), conditioning=c, eta=eta, temperature=temp, x_T=x.cuda(), verbose=False,
+                                  unconditional_guidance_scale=scale, unconditional_conditioning=ucond)
+        finally:
+            model.sample_use_graph = True
+        assert torch.equal(out_e, out)
+        del used[:]
+        fast = model.sample_loop_fast                      # the per-step host loop (p_sample_ddim -> mkd_ddim_step): what a callback gets
+        out_h, _ = smp.sample(S, x.shape[0], tuple(x.shape[1:]), conditioning=c, eta=eta, temperature=temp, x_T=x.cuda(), verbose=False,
+                              unconditional_guidance_scale=scale, unconditional_conditioning=ucond, callback=lambda i: None)
+        assert fast is not None and used == list(range(S)) and torch.equal(out_h, out)
+        del used[:]
         det, _ = smp.sample(S, x.shape[0], tuple(x.shape[1:]), conditioning=c, eta=0.0, x_T=x.cuda(), verbose=False,
                             unconditional_guidance_scale=scale, unconditional_conditioning=ucond)
         assert metrics(det, ref)[0] > 5e-2                 # the noise does move the latent: not a vacuous comparison
