@@ -168,7 +168,7 @@ def pmc_traffic_bytes_per_launch(kernel_fn, live=None, live_note=None, tag='b8_2
 def l2_traffic_per_eval(tag, attn_launches_per_eval):
     """L2 -> CU traffic of ONE eps evaluation from the committed rocprofv3 summaries of this workload (tag): per kernel, (TCC_HIT_sum +
     TCC_MISS_sum) requests per launch (profiles/r4_pmc_l2_hit_<tag>.csv, 128 B each) x its launches per evaluation.  The number of
-    evaluations inside the profiled run is DERIVED: calls of attention_kernel in the run / attention launches of one
+    evaluations inside the profiled run is DERIVED: calls of the attention kernels in the run / attention launches of one
     evaluation in this run's plan - the profiled bench also runs eps_profile passes beside the loop.  None when the summaries are
     absent."""
     import csv
@@ -180,7 +180,7 @@ def l2_traffic_per_eval(tag, attn_launches_per_eval):
         for r in csv.DictReader(open(f_stats)):
             n = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
             stats[n] = stats.get(n, 0) + int(r['Calls'])
-        attn_calls = sum(v for k, v in stats.items() if k.startswith('attention_kernel'))
+        attn_calls = sum(v for k, v in stats.items() if k.startswith('attention_'))      # (attention_kernel<...>, attention_dma40_kernel<...>)
         evals = attn_calls / float(attn_launches_per_eval)
         if evals < 1:
             return None
