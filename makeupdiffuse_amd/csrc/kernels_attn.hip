@@ -469,6 +469,9 @@ __global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo>
         const int per = isv ? 6 : 5;
         srow[i] = pp / per; scol[i] = (pp - srow[i] * per) * 8; sv[i] = isv; sone[i] = isv && scol[i] == 40;
     }
+    // (all of a tile's wave-instructions are issued together right behind the barrier: 516 cycles per wave and 128-key tile in the phase
+    // trace, profiles/exp_r4_attn_trace_dma.txt - an LDS-DMA instruction costs its wave ~170 cycles of issue wherever it stands: spread
+    // one by one between the QK^T / softmax / P.V phases the same cycles reappear inside those phases, 330 -> 341 us at 4096 keys)
     auto issue = [&](int buf, int key0) {
         char* dst = smem + buf * D::TILE_BYTES;
 #pragma unroll
@@ -509,11 +512,18 @@ __global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo>
     float m_ref = 0.f;
     const int k1s = g == 0 ? 16 * D::KROW : 0;          // second K fragment: the tile's chunk 4 (g = 0) or the constant ones block
 
+#ifdef MKD_ATTN_TRACE
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
+        ATT_T(6);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's part of tile t has landed
+        ATT_T(0);
         __syncthreads();                                       // ... and everyone's; tile t - 1 is consumed: its buffer is free
+        ATT_T(1);
         if (t + 1 < ntiles) issue((t + 1) & 1, key0 + KT);
+        ATT_T(3);
         const char* ks = smem + (t & 1) * D::TILE_BYTES;
         const char* vs = ks + D::KSLOTS * 16;
 
@@ -530,6 +540,10 @@ __global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo>
                 st[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1], st[mf], 0, 0, 0);
             }
         }
+#ifdef MKD_ATTN_TRACE
+        asm volatile("" :: "v"(st[0]), "v"(st[KB - 1]));
+#endif
+        ATT_T(4);
         // st = s c - m_ref (see attention_kernel, AttnCfg::OFFS)
         {
             float mx = -INFINITY;
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo>
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[mf][r] = __builtin_amdgcn_exp2f(st[mf][r]);
         }
+        ATT_T(5);
         // O^T[d][q] += V^T[d][key'] P^T[key'][q] (attention_kernel's operand order)
 #pragma unroll
         for (int s = 0; s < KT / 32; ++s) {
@@ -589,6 +604,13 @@ __global__ __launch_bounds__(512) void attention_dma40_kernel(const Pair<AttnIo>
             }
         }
     }
+#ifdef MKD_ATTN_TRACE
+    ATT_T(6);
+    if (g_attn_trace_dev && lane == 0) {
+        long long* o_ = g_attn_trace_dev + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + w) * 8;
+        for (int i = 0; i < 8; ++i) o_[i] = tacc[i];
+    }
+#endif
     const float l_run = __shfl(oacc[2][0], 32 + qc, 64);        // row 40 of O^T: fragment 2, lane group 2, register 0
     const float inv = 1.0f / l_run;
     if (qi < Tq) {

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from makeupdiffuse_amd import lib as mlib
 lib = mlib.load(); P = lambda t: C.c_void_p(t.data_ptr())
 NAMES = ['barrier 1', 'LDS stores', 'barrier 2', 'prefetch issue', 'QK^T', 'softmax', 'P.V + tail']
+# (LDS-DMA kernel, dh 40 from 1024 keys: 'barrier 1' = wait for this thread's DMA, 'LDS stores' = the barrier, 'barrier 2' unused, 'prefetch issue' = DMA issue; tiles of 128 keys)
 for (B, T, H, dh) in ((8, 4096, 8, 40), (8, 1024, 8, 40), (8, 1024, 8, 80)):
     d = H * dh
     q = torch.randn(B * T, d, device='cuda').bfloat16(); k = torch.randn(B * T, d, device='cuda').bfloat16(); v = torch.randn(B * T, d, device='cuda').bfloat16(); o = torch.empty_like(q)
@@ -18,7 +19,7 @@ for (B, T, H, dh) in ((8, 4096, 8, 40), (8, 1024, 8, 40), (8, 1024, 8, 80)):
     torch.cuda.synchronize()
     t = tr.cpu().double()
     tot = t[:, :, :7].sum(-1)
-    ntile = T // 64
+    ntile = T // (128 if dh == 40 and os.environ.get('MKD_ATTN_DMA', '1') != '0' else 64)
     print(f'B={B} T={T} dh={dh}: cycles per wave per tile {tot.mean().item() / ntile:.0f}: ' +
           ' | '.join(f'{NAMES[i]} {t[:, :, i].mean().item() / ntile:.0f}' for i in range(7)))
     lib.mkd_debug_attn_trace(None)
