@@ -809,6 +809,14 @@ struct mkd_ctx {
         const size_t mk = TA().mark();
         const int rows = x.rows(), hw = x.H * x.W;
         Tensor t4;
+#ifdef MKD_EXP_ABLATE
+        // experiment build only (MKD_EXP_SKIP & 32): no skip_connection GEMMs - conv2 takes its own input as residual (WRONG results):
+        // the bound for folding the 1x1 skip into conv2's K loop
+        static const bool no_skip = getenv("MKD_EXP_SKIP") && (atoi(getenv("MKD_EXP_SKIP")) & 32);
+#else
+        constexpr bool no_skip = false;
+#endif
+        if (no_skip && x.C != cout) side_skip = false;
         if (x.C != cout && side_skip) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
             op_edge(lane_main, helper_stream);           // helper stream waits for the block input (written on the lane's stream)
@@ -833,6 +841,8 @@ struct mkd_ctx {
         if (x.C != cout && side_skip) {
             op_edge(helper_stream, lane_main);           // the lane waits for the skip GEMM
             e2.R = t4.p; e2.ldr = t4.ld;
+        } else if (x.C != cout && no_skip) {
+            e2.R = t3.p; e2.ldr = t3.ld;
         } else if (x.C != cout) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
             Epi es; es.bias = wf(p + ".skip_connection.bias");
