@@ -83,6 +83,8 @@ int mkd_param_shape(const mkd_ctx* ctx, int index, int64_t* shape4);
  * give the initial values).  Takes effect at the next mkd_prepare (the launch plan is re-built).  Names:
  *   "tfm_tail"             fused row-local transformer tail: 0 off, 1 wherever the kernel covers the shape, -1 shape policy (default)
  *   "tfm_tail_min_rows"    ... the policy's threshold on the rows (samples x tokens) of a block (default 4096)
+ *   "skip_fold"            ... ResBlocks with a 1x1 skip_connection: conv2 and the skip as one implicit GEMM (K = 9 Cout + Cin) where
+ *                          conv2's plan is the gather kernel: 0 off, 1 on (default)
  *   "tfm_head"             ... and the block's head (GroupNorm apply + proj_in + LayerNorm 1 . q|k|v) as one launch behind a GroupNorm
  *                          statistics launch wherever the tail is fused: 0 off, 1 on (default)
  *   "gn_2k_min_hw"         GroupNorm over >= this many pixels per sample: two full-chip launches (default 4096)
@@ -214,6 +216,14 @@ int mkd_eps_profile2(mkd_ctx* ctx, const float* x, const int64_t* t, float* eps_
                      double* ms_back_to_back_per_kind, const char* csv_path);
 /* Bytes of device memory held by the context (weights + workspace). */
 int64_t mkd_device_bytes(const mkd_ctx* ctx);
+
+/* ResBlock tail as ONE implicit GEMM (UPSTREAM ResBlock._forward: out = conv3x3(h) + skip_connection(x), the 1x1 skip of the blocks whose
+ * channel count changes; reached from diffmk/makeup_diffuse.py:164-168): y[m, :] = conv3x3(x)[m, :] + x2[m, :] . W_skip^T + bias.
+ * w_fold: [N][9 * Cin + K2] bf16, row n = (the packed 3x3 weight row of mkd_pack_conv_weight, tap-major) | W_skip[n, :]; x [batch*H*W, Cin]
+ * and x2 [batch*H*W, K2] NHWC at ldx / ldx2; stride 1, pad 1.  Runs on the gather kernel (tile plan of the plain convolution);
+ * MKD_ERR_UNSUPPORTED when that shape's plan is an LDS-staged tile. */
+int mkd_conv3x3_fold_bf16(const uint16_t* x, int ldx, const uint16_t* w_fold, const float* bias, const uint16_t* x2, int ldx2, int K2,
+                          uint16_t* y, int ldy, int batch, int H, int W, int Cin, int N, int splitk, void* stream);
 
 /* ---- single kernels (unit parity tests; bf16 = uint16_t device buffers) -------------------- */
 /* C[M,N] = act((A[M,K] . W[N,K]^T + bias[N] + rowbias[m / rows_per_batch][n]) * scale + R[M,N]).

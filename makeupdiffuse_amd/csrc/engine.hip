@@ -179,6 +179,10 @@ struct mkd_ctx {
     // launch: 4 launches -> 2): tfm_head 0 off, 1 wherever the tail is fused (default)
     int tfm_head = getenv("MKD_TFM_HEAD") ? atoi(getenv("MKD_TFM_HEAD")) : 1;
     std::map<std::string, bf16_t*> tfm_hw; std::map<std::string, float*> tfm_hv;
+    // ResBlocks with a 1x1 skip_connection: conv2 and the skip as ONE implicit GEMM over K = 9 Cout + Cin_block (GemmArgs::A2) where
+    // conv2's plan is the gather kernel - [W_conv2 | W_skip] and b_conv2 + b_skip built at load time.  skip_fold: 0 off, 1 on (default)
+    int skip_fold = getenv("MKD_SKIP_FOLD") ? atoi(getenv("MKD_SKIP_FOLD")) : 1;
+    std::map<std::string, bf16_t*> fold_w; std::map<std::string, float*> fold_b;
     std::map<std::string, float*> f32_keep;      // fp32 copies of the weights that get folded (kept for re-finalize)
     bf16_t* emb_w[2] = {nullptr, nullptr};
     float* emb_b[2] = {nullptr, nullptr};
@@ -515,7 +519,7 @@ struct mkd_ctx {
         }
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
         q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear(); ffm_w.clear(); ffm_b.clear();
-        tfm_w.clear(); tfm_v.clear(); tfm_hw.clear(); tfm_hv.clear();
+        tfm_w.clear(); tfm_v.clear(); tfm_hw.clear(); tfm_hv.clear(); fold_w.clear(); fold_b.clear();
         for (int which = 0; which < 2; ++which) {
             for (auto& p : st_prefixes[which]) {
                 const std::string t = p + ".transformer_blocks.0";
@@ -622,6 +626,26 @@ struct mkd_ctx {
                     if (rc) return rc;
                     tfm_hw[p] = (bf16_t*)hwp; tfm_hv[p] = (float*)hvp;
                 }
+            }
+            for (auto& p : res_prefixes[which]) {
+                auto sk = params.find(p + ".skip_connection.weight");
+                if (sk == params.end()) continue;
+                const Param& cw = params.at(p + ".out_layers.3.weight");
+                const int cout = (int)cw.shape[0], cs = (int)sk->second.shape[1];
+                if (cw.shape[1] != cout || (9 * cout) % 64 || cs % 64) continue;
+                const size_t kc = (size_t)9 * cout, kt = kc + cs;
+                void* wm = nullptr; void* bm = nullptr;
+                int rc = dev_alloc(&wm, (size_t)cout * kt * sizeof(bf16_t)); if (rc) return rc;
+                rc = dev_alloc(&bm, (size_t)cout * sizeof(float)); if (rc) return rc;
+                MKD_HIP_CHECK(hipMemcpy2D(wm, kt * sizeof(bf16_t), cw.dev, kc * sizeof(bf16_t), kc * sizeof(bf16_t), cout, hipMemcpyDeviceToDevice));
+                MKD_HIP_CHECK(hipMemcpy2D((char*)wm + kc * sizeof(bf16_t), kt * sizeof(bf16_t), sk->second.dev, (size_t)cs * sizeof(bf16_t), (size_t)cs * sizeof(bf16_t), cout,
+                                          hipMemcpyDeviceToDevice));
+                std::vector<float> b1(cout), b2(cout);
+                MKD_HIP_CHECK(hipMemcpy(b1.data(), wf(p + ".out_layers.3.bias"), cout * sizeof(float), hipMemcpyDeviceToHost));
+                MKD_HIP_CHECK(hipMemcpy(b2.data(), wf(p + ".skip_connection.bias"), cout * sizeof(float), hipMemcpyDeviceToHost));
+                for (int i = 0; i < cout; ++i) b1[i] += b2[i];
+                MKD_HIP_CHECK(hipMemcpy(bm, b1.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+                fold_w[p] = (bf16_t*)wm; fold_b[p] = (float*)bm;
             }
             std::vector<std::string> wn;
             int off = 0;
@@ -817,6 +841,18 @@ struct mkd_ctx {
         constexpr bool no_skip = false;
 #endif
         if (no_skip && x.C != cout) side_skip = false;
+        // conv2 + skip as one implicit GEMM when conv2's plan for this shape is the gather kernel (the decoder lanes' shapes)
+        GemmArgs fa; memset(&fa, 0, sizeof(fa));
+        bool fold = false;
+        if (x.C != cout && skip_fold && !no_skip && fold_w.count(p) && x.ld % 8 == 0) {
+            Tensor t3s; t3s.p = nullptr; t3s.B = x.B; t3s.H = x.H; t3s.W = x.W; t3s.C = cout; t3s.ld = cout;
+            Epi ef; ef.bias = fold_b.at(p); ef.gn = go;
+            fa = conv_args(t3s, fold_w.at(p), cout, 1, 0, ef, out, ldo);
+            fa.A2 = x.p; fa.lda2 = x.ld; fa.K2 = x.C; fa.K += x.C; fa.ldw = fa.K; fa.zero = zero_page;
+            int cfg_i = 0, sk_i = 1;
+            fold = gemm_resolve(fa, &cfg_i, &sk_i) == 0;
+        }
+        if (fold) side_skip = false;
         if (x.C != cout && side_skip) {
             t4 = talloc(TA(), x.B, x.H, x.W, cout);
             op_edge(lane_main, helper_stream);           // helper stream waits for the block input (written on the lane's stream)
@@ -836,6 +872,12 @@ struct mkd_ctx {
                              wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld)) {
             op_conv(t1, wb(p + ".in_layers.2.weight"), cout, 1, 0, e1, t2.p, t2.ld);
             op_gn(t2, wf(p + ".out_layers.0.weight"), wf(p + ".out_layers.0.bias"), 1e-5f, 1, t3.p, t3.ld);
+        }
+        if (fold) {
+            fa.A = t3.p; fa.lda = t3.ld;
+            op_gemm(fa);
+            TA().release(mk);
+            return;
         }
         Epi e2; e2.bias = wf(p + ".out_layers.3.bias"); e2.gn = go;
         if (x.C != cout && side_skip) {
@@ -2510,6 +2552,7 @@ int mkd_ctx_set_option(mkd_ctx* ctx, const char* name, double value) {
     if (n == "tfm_tail") ctx->tfm_tail = iv;
     else if (n == "tfm_tail_min_rows") ctx->tfm_tail_min_rows = iv;
     else if (n == "tfm_head") ctx->tfm_head = iv;
+    else if (n == "skip_fold") ctx->skip_fold = iv;
     else if (n == "gn_2k_min_hw") ctx->gn_2k_min_hw = iv;
     else if (n == "xcd_auto_ratio") ctx->xcd_auto_ratio = (float)value;
     else if (n == "dec_lanes") { if (iv != 0 && iv != 2 && iv != 4) return mkd_fail(MKD_ERR_ARG, "dec_lanes: 0, 2 or 4"); ctx->dec_lanes = iv; }
@@ -2526,6 +2569,7 @@ int mkd_ctx_get_option(const mkd_ctx* ctx, const char* name, double* value) {
     if (n == "tfm_tail") *value = ctx->tfm_tail;
     else if (n == "tfm_tail_min_rows") *value = ctx->tfm_tail_min_rows;
     else if (n == "tfm_head") *value = ctx->tfm_head;
+    else if (n == "skip_fold") *value = ctx->skip_fold;
     else if (n == "gn_2k_min_hw") *value = ctx->gn_2k_min_hw;
     else if (n == "xcd_auto_ratio") *value = ctx->xcd_auto_ratio;
     else if (n == "dec_lanes") *value = ctx->dec_lanes;
@@ -2640,6 +2684,25 @@ int mkd_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const 
                   int splitk, void* stream) {
     return gemm_entry(A, lda, W, ldw, bias, rowbias, ldrb, rows_per_batch, R, ldr, scale, act, C, ldc, out_f32, M, N, K, conv3x3, batch,
                       Hin, Win, Cin, Hout, Wout, stride, up, splitk, nullptr, 0, 0, 0, stream);
+}
+int mkd_conv3x3_fold_bf16(const uint16_t* x, int ldx, const uint16_t* w_fold, const float* bias, const uint16_t* x2, int ldx2, int K2, uint16_t* y,
+                          int ldy, int batch, int H, int W, int Cin, int N, int splitk, void* stream) {
+    if (!x || !w_fold || !x2 || !y) return mkd_fail(MKD_ERR_ARG, "mkd_conv3x3_fold_bf16: null pointer");
+    if (!g_zero) {
+        MKD_HIP_CHECK(hipMalloc((void**)&g_zero, 4096));
+        MKD_HIP_CHECK(hipMemset(g_zero, 0, 4096));
+    }
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.A = x; a.lda = ldx; a.W = w_fold; a.ldw = 9 * Cin + K2; a.bias = bias; a.scale = 1.0f; a.C = y; a.ldc = ldy; a.M = batch * H * W; a.N = N;
+    a.K = 9 * Cin + K2; a.conv = 1; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = H; a.Wout = W; a.stride = 1; a.up = 0;
+    a.A2 = x2; a.lda2 = ldx2; a.K2 = K2; a.zero = g_zero; a.splitk = splitk > 0 ? splitk : 0;
+    int cfg_i = 0, s = 1;
+    int rc = gemm_resolve(a, &cfg_i, &s);
+    if (rc) return rc;
+    rc = scratch(&g_ws, &g_ws_bytes, gemm_ws_bytes(a.M, N, s > 1 ? s : 2));
+    if (rc) return rc;
+    a.ws = g_ws; a.ws_bytes = g_ws_bytes;
+    return launch_gemm(a, (hipStream_t)stream);
 }
 int mkd_gemm_gnstat_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* rowbias, int ldrb,
                          int rows_per_batch, const uint16_t* R, int ldr, float scale, int act, void* C, int ldc, int out_f32, int M,

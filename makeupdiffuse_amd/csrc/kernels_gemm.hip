@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
     const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
     const int lda = p.lda, ldw = p.ldw, M = p.M, N = p.N, K = p.K;
     const int Hin = p.Hin, Win = p.Win, Cin = p.Cin, Hout = p.Hout, Wout = p.Wout, cstride = p.stride, up = p.up;
+    const bf16_t* const gA2 = p.A2; const int lda2 = p.lda2; const int Kc = K - p.K2;      // CONV: columns [Kc, K) contract with the second input (folded 1x1)
     const int splitk = p.splitk, per = p.ksteps_per_split;
     float* const ws = p.ws;
     const Epilogue epi = make_epilogue(p);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
         const int k = kt * BK + sc * 8;
         const bool kok = k < K && kt < kt_end;                // (KW > 1: the last round may have no tile for this group)
         int ci = 0, ky = 0, kx = 0;
+        const bool second = CONV && k >= Kc;          // (uniform per K-step: Kc is a multiple of BK)
         if (CONV) {
             const int tap = k / Cin;
             ci = k - tap * Cin;
@@ -139,7 +141,10 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void gemm_kernel(const GemmArgs2
         for (int i = 0; i < XP; ++i) {
             const bf16_t* real;
             bool ok;
-            if (CONV) {
+            if (CONV && second) {          // folded 1x1: the output pixel's own row of the second input (stride 1: input pixel (uy0 + 1, ux0 + 1))
+                ok = kok && xok[i];
+                real = gA2 + ((xoff[i] + (size_t)((uy0[i] + 1) * Win + ux0[i] + 1)) * lda2 + (k - Kc));
+            } else if (CONV) {
                 const int uy = uy0[i] + ky, ux = ux0[i] + kx;
                 ok = kok && xok[i] && (unsigned)uy < (unsigned)Hup && (unsigned)ux < (unsigned)Wup;
                 real = gA + ((xoff[i] + (size_t)((uy >> up) * Win + (ux >> up))) * lda + ci);
@@ -906,6 +911,7 @@ static const char* const kTileName[N_TILE_CFG] = {"256x128", "128x128_s3", "128x
                                                   "patch128x64_w8", "patch64x128_w8", "patch128x128_w8", "256x64_w8", "patch256x128_w16", "patch128x128_w16",
                                                   "ra256x64_w8", "ra256x128_w8", "ra128x128", "ra128x64", "ra128x160", "ra256x64", "256x256_w16"};
 static bool is_patch_cfg(int c) { return (c >= 6 && c <= 11) || (c >= 38 && c <= 40) || c == 42 || c == 43; }
+bool gemm_cfg_folds_second_input(int c) { return c >= 0 && c < N_TILE_CFG && !is_patch_cfg(c) && !(c >= 44 && c <= 49); }      // gemm_kernel (GemmArgs::A2)
 int gemm_num_tile_cfgs() { return N_TILE_CFG; }
 const char* gemm_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < N_TILE_CFG) ? kTileName[cfg] : "?"; }
 
@@ -958,14 +964,15 @@ void gemm_force_tile_cfg(int cfg) {
 // which is what bounds these kernels); problems that cannot fill the 256 CUs step down to smaller tiles
 // and only then split K (fp32 partial slabs cost 8 B per output element per slice).
 // pin_cfg >= 0: that tile configuration, split-K by the heuristic, tuned table / overrides / g_force_cfg ignored
-static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, int stride = 0, int up = 0, int pin_cfg = -1) {
+static GemmPlan gemm_plan(int M, int N, int K, int force_splitk, int conv = 0, int stride = 0, int up = 0, int pin_cfg = -1, int K2 = 0) {
     const int nk = (K + BK - 1) / BK;
+    const int KL = K - K2;          // the tables know the plain convolution (GemmArgs::K2)
     auto tiles = [&](int c) { return ((M + kTileM[c] - 1) / kTileM[c]) * ((N + kTileN[c] - 1) / kTileN[c]); };
     int cfg;
     const int g_force_cfg = pin_cfg >= 0 ? pin_cfg : ::g_force_cfg;          // (shadows the global on purpose)
-    const TunedEntry* te = (g_force_cfg < 0 && force_splitk <= 0) ? tuned_lookup(M, N, K, conv, stride, up) : nullptr;
+    const TunedEntry* te = (g_force_cfg < 0 && force_splitk <= 0) ? tuned_lookup(M, N, KL, conv, stride, up) : nullptr;
     if (g_force_cfg < 0 && force_splitk <= 0 && !g_override.empty()) {
-        auto it = g_override.find(ShapeKey{M, N, K, conv, stride, up});
+        auto it = g_override.find(ShapeKey{M, N, KL, conv, stride, up});
         if (it != g_override.end()) te = &it->second;
     }
     if (te) {
@@ -1035,7 +1042,9 @@ static GemmPlan stat_producer_plan(GemmPlan g) {
 // this at plan time and launch_gemm takes the same decision at launch time.  A tuned LDS-patch entry whose spatial tiling does
 // not fit THIS geometry (the table is keyed on M, N, K only) falls back to the generic 128x128 tile with heuristic split-K.
 static int gemm_resolve_plan(const GemmArgs& a, GemmPlan* out) {
-    GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0);
+    GemmPlan g = gemm_plan(a.M, a.N, a.K, a.splitk, a.conv, a.conv ? a.stride : 0, a.conv ? a.up : 0, -1, a.A2 ? a.K2 : 0);
+    if (a.A2 && !gemm_cfg_folds_second_input(g.cfg))
+        return mkd_fail(-4, "gemm: a convolution with a folded second input runs on the gather kernel only (the plan of this shape is LDS-staged or register-A)");
     if (a.ln_s && g.splitk > 1) {          // the LN correction is applied on the full-K accumulator
         g.splitk = 1;
         g.per = (a.K + BK - 1) / BK;
@@ -1182,7 +1191,7 @@ bool gemm_same_geometry(const GemmArgs& a, const GemmArgs& b) {
            a.out_f32 == b.out_f32 && a.act == b.act && a.ldc == b.ldc && a.defer_epilogue == b.defer_epilogue && a.rows_per_batch == b.rows_per_batch &&
            (a.ln_s != nullptr) == (b.ln_s != nullptr) && a.ln_eps == b.ln_eps && !a.stat_in && !b.stat_in && !a.stat_out && !b.stat_out &&
            !a.gn_stat && !b.gn_stat && (a.R != nullptr) == (b.R != nullptr) && a.ldr == b.ldr && (a.rowbias != nullptr) == (b.rowbias != nullptr) &&
-           (a.bias != nullptr) == (b.bias != nullptr);
+           (a.bias != nullptr) == (b.bias != nullptr) && (a.A2 != nullptr) == (b.A2 != nullptr) && a.K2 == b.K2 && a.lda2 == b.lda2;
 }
 
 template <int TM, int TN, int NW, int STAGES>
@@ -1207,7 +1216,10 @@ int launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return mkd_fail(-1, "gemm: empty problem");
     if (a.N % 4) return mkd_fail(-1, "gemm: N must be a multiple of 4");
     if (a.K % 8 || a.ldw % 8 || a.lda % 8) return mkd_fail(-1, "gemm: K, lda, ldw must be multiples of 8");
-    if (a.conv && (a.Cin % 8 || a.K != 9 * a.Cin)) return mkd_fail(-1, "gemm: conv needs Cin % 8 == 0 and K == 9*Cin");
+    if (a.A2 && (!a.conv || a.stride != 1 || a.up != 0 || a.K2 <= 0 || a.K2 % BK || (9 * a.Cin) % BK || a.lda2 % 8 || a.Hin != a.Hout || a.Win != a.Wout))
+        return mkd_fail(-1, "gemm: a folded second input needs a stride-1 conv3x3 and K2, 9 * Cin multiples of 64");
+    if (!a.A2) a.K2 = 0;
+    if (a.conv && (a.Cin % 8 || a.K != 9 * a.Cin + a.K2)) return mkd_fail(-1, "gemm: conv needs Cin % 8 == 0 and K == 9*Cin (+ K2)");
     if (!a.zero) return mkd_fail(-1, "gemm: zero page missing");
     if (!a.out_f32 && (a.ldc % 4)) return mkd_fail(-1, "gemm: ldc must be a multiple of 4");
     if (a.act == 2 && (a.out_f32 || a.R)) return mkd_fail(-1, "gemm: GEGLU epilogue takes no residual and writes bf16");

@@ -92,6 +92,10 @@ struct GemmArgs {
     int xcd_mode;
     int gz;               // z extent of ONE problem's grid (set by the launchers); a grouped launch stacks the second problem above it
     const bf16_t* zero;   // >= 16 bytes of zeros
+    // conv3x3 with a folded 1x1 convolution of a SECOND input (ResBlock: out = conv3x3(h) + skip_connection(x), UPSTREAM ResBlock._forward):
+    // K = 9 * Cin + K2, W = [W_conv | W_skip] (row-major over that K), the last K2 columns contract with row m of A2 ([M, K2] at lda2).
+    // Gather / linear kernel only (stride 1, no upsampling); the tile plan is the one of the plain convolution (K - K2 in the tables)
+    const bf16_t* A2; int lda2; int K2;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -138,6 +142,7 @@ struct TembSel { const float* tab[2]; float* proj[2]; int n[2]; int batch; };
 int  launch_gemm(GemmArgs a, hipStream_t stream, const GemmArgs* second = nullptr);
 bool gemm_same_geometry(const GemmArgs& a, const GemmArgs& b);     // may the two run as one grouped launch?
 int  gemm_pick_splitk(int M, int N, int K, int conv, int stride, int up);
+bool gemm_cfg_folds_second_input(int cfg);     // may this tile configuration take GemmArgs::A2 (gather / linear kernel)?
 int  gemm_resolve(const GemmArgs& a, int* cfg, int* splitk);       // the (tile, split-K) launch_gemm will use for exactly these arguments
 int  gemm_stat_slots(int M, int N, int K);   // column slots a linear GEMM of this shape writes row statistics in
 int  gemm_tile_index(int M, int N, int K, int conv, int stride, int up);   // index into the tile-config table of kernels_gemm.hip

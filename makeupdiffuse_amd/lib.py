@@ -84,6 +84,7 @@ SIGNATURES = {
     'mkd_device_bytes': (_L, [_P]),
     'mkd_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                            _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'mkd_conv3x3_fold_bf16': (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mkd_gemm_gnstat_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _I, _I,
                                   _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     'mkd_gemm_groupnorm_bf16': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I,

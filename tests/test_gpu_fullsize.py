@@ -118,6 +118,16 @@ def test_full_size_fused_transformer_tail_equals_the_seven_launch_plan(full):
                 rh = rel(a_on, a)
                 print(f'fused head vs 4 launches: eps batch 8 rel-L2 {rh:.3e}')
                 assert on.eps_launches() - n_on == 20 and rh <= 2e-2
+        # ... and the ResBlocks' 1x1 skip_connection folded into conv2's K loop where conv2 runs on the gather kernel (the decoder
+        # lanes' shapes): off, the skip GEMMs (and their split-K reduces) are launches of their own again
+        on.set_option('tfm_head', 1)
+        on.set_option('skip_fold', 0)
+        on.prepare(I['hint'], I['ctx'])
+        a = on.eps(I['x'], I['t'])
+        rs = rel(a_on, a)
+        print(f'folded skip vs separate skip GEMMs: eps batch 8 rel-L2 {rs:.3e}, launches {n_on} vs {on.eps_launches()}')
+        assert on.eps_launches() - n_on >= 20 and rs <= 2e-2
+        on.set_option('skip_fold', 1)
     finally:
         off.close(); on.close()
 

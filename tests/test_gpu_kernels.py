@@ -733,3 +733,39 @@ def test_xcd_tile_order_is_a_permutation_of_the_tiles(mode):
             lib.mkd_gemm_set_xcd_mode(0)
             lib.mkd_gemm_force_tile(-1)
         assert torch.equal(out, ref), f'xcd mode {mode}, cfg {cfg}: differs from the launch order'
+
+
+@pytest.mark.parametrize('cfg,B,H,W_,Cin,K2,pad2,splitk', [(-1, 2, 8, 8, 64, 128, 0, 0), (5, 1, 16, 16, 64, 192, 64, 0), (3, 2, 16, 16, 128, 64, 0, 2),
+                                                         (24, 3, 8, 8, 128, 256, 0, 0), (28, 2, 16, 16, 64, 128, 8, 0), (34, 1, 32, 32, 64, 64, 0, 0),
+                                                         (19, 1, 4, 4, 128, 320, 0, 3)])
+def test_conv3x3_with_folded_skip(cfg, B, H, W_, Cin, K2, pad2, splitk):
+    """ResBlock tail as ONE implicit GEMM (round 4): conv3x3(h) + skip_connection(x) over K = 9 Cin + K2 on the gather kernel
+    (GemmArgs::A2; UPSTREAM ResBlock._forward, reached from /root/reference/diffmk/makeup_diffuse.py:164-168) against torch
+    conv2d + a 1x1 conv2d of the second input: plain, in-block K split, split-K and eight-wave tiles, ragged tiles, a padded stride of
+    the second input (the decoder's concat buffers)."""
+    lib = L()
+    Cout = Cin
+    g = torch.Generator().manual_seed(cfg * 7 + B * H + K2)
+    h = bf(torch.randn(B, Cin, H, W_, generator=g)); x2 = bf(torch.randn(B, K2, H, W_, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)); ws = bf(torch.randn(Cout, K2, generator=g) / math.sqrt(K2))
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    wp = torch.empty(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)
+    assert lib.mkd_pack_conv_weight(P(w.float().contiguous()), P(wp), Cout, Cin, 3, 3, None) == 0
+    sync()
+    wf = torch.cat([wp, ws], 1).contiguous()
+    hn = h.permute(0, 2, 3, 1).contiguous()
+    ld2 = K2 + pad2
+    x2n = torch.full((B, H, W_, ld2), float('nan'), device=DEV, dtype=torch.bfloat16)
+    x2n[..., :K2] = x2.permute(0, 2, 3, 1)
+    ref = F.conv2d(h.float(), w.float(), bias, padding=1) + F.conv2d(x2.float(), ws.float()[:, :, None, None])
+    out = torch.zeros(B * H * W_, Cout, device=DEV, dtype=torch.bfloat16)
+    lib.mkd_gemm_force_tile(cfg)
+    try:
+        rc = lib.mkd_conv3x3_fold_bf16(P(hn), Cin, P(wf), P(bias), P(x2n), ld2, K2, P(out), Cout, B, H, W_, Cin, Cout, splitk, None)
+        assert rc == 0, lib.mkd_last_error()
+        sync()
+        lib.mkd_gemm_force_tile(9)                   # an LDS-staged tile cannot take the second input: refused, not computed wrongly
+        assert lib.mkd_conv3x3_fold_bf16(P(hn), Cin, P(wf), P(bias), P(x2n), ld2, K2, P(out.clone()), Cout, B, H, W_, Cin, Cout, 0, None) != 0
+    finally:
+        lib.mkd_gemm_force_tile(-1)
+    assert_close_bf16(out.float().view(B, H, W_, Cout).permute(0, 3, 1, 2), ref, what=f'conv3x3 + folded 1x1 skip, cfg {cfg}')
