@@ -454,6 +454,7 @@ def main():
             'loop': {'ms_per_eval': loop_ms / evals_per_step, 'executed_tflop_per_eval': eps_flops / 1e12,
                      'mfma_tflops_whole_loop': loop_tflops, 'mfma_frac_whole_loop': loop_tflops / PEAK_BF16_TFLOPS,
                      'launches_per_eval': eng.step_launches(use_graph=bool(args.graph), cfg=bool(args.cfg)) / (2 if args.cfg else 1), 'launches_per_step': eng.step_launches(use_graph=bool(args.graph), cfg=bool(args.cfg)),
+                     'plan_options': {k: eng.get_option(k) for k in ('tfm_tail', 'tfm_tail_min_rows', 'tfm_head', 'skip_fold', 'dec_lanes', 'ln_fly', 'gn_2k_min_hw', 'gn_slab_min_channels', 'xcd_auto_ratio', 'graph_steps')},
                      'launches_per_standalone_eps': eng.eps_launches(),
                      'device_gb': eng.device_bytes() / 1e9,
                      'hipgraph': bool(args.graph), 'vae_decode': bool(args.decode),

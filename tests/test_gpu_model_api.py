@@ -286,3 +286,29 @@ def test_sample_rejects_a_latent_that_does_not_match_the_prepared_hint(model, G)
         eng.sample(torch.randn(1, 4, 8, 8), *args)             # wrong batch
     with pytest.raises(ValueError):
         eng.sample(torch.randn(2, 4, 8, 8), *args, cfg_scale=9.0)     # CFG needs a 2B prepared batch
+
+
+def test_mkd_sample_eta_rejects_bad_arguments(model, G):
+    """mkd_sample_eta (round 4): sigma > 0 without noise draws, a sigma that makes 1 - a_prev - sigma^2 negative and a noise tensor of the
+    wrong shape are refused, loudly; all sigmas 0 is mkd_sample bit for bit."""
+    from makeupdiffuse_amd import lib as mlib
+    x = G['x'].cuda()
+    eng = model._bind_cond(cond_of(G), x.shape[2:])
+    sch = model.schedule
+    sch.make_ddim(4, ddim_eta=0.0)
+    args = ([int(v) for v in sch.ddim_timesteps], [float(v) for v in sch.ddim_alphas], [float(v) for v in sch.ddim_alphas_prev],
+            [float(v) for v in sch.ddim_sqrt_one_minus_alphas])
+    base = eng.sample(x, *args)
+    assert torch.equal(eng.sample(x, *args, sigmas=[0.0] * 4, noise=None), base)
+    with pytest.raises(ValueError):
+        eng.sample(x, *args, sigmas=[0.1] * 4, noise=None)
+    with pytest.raises(ValueError):
+        eng.sample(x, *args, sigmas=[0.1] * 4, noise=torch.zeros(3, *x.shape))
+    with pytest.raises(mlib.MkdError):
+        eng.sample(x, *args, sigmas=[5.0] * 4, noise=torch.zeros(4, *x.shape))
+    sch.make_ddim(4, ddim_eta=0.5)
+    sg = [float(v) for v in sch.ddim_sigmas]
+    assert min(sg) >= 0 and max(sg) > 0
+    z = eng.sample(x, *args, sigmas=sg, noise=torch.zeros(4, *x.shape), use_graph=True)      # zero draws: only dir_xt changes
+    assert torch.isfinite(z).all() and not torch.equal(z, base)
+    sch.make_ddim(4, ddim_eta=0.0)
