@@ -430,9 +430,13 @@ struct mkd_ctx {
     }
 
     // ---- weights ----------------------------------------------------------------------------------
+    // Weight forms DERIVED at finalize() (concatenated / folded / packed copies) are rebuilt by every finalize after a weight was
+    // loaded: they live in their own list and the previous generation is freed first (a reloaded checkpoint must not leave 1-2 GB of
+    // stale copies behind; no plan can still use them: mkd_load_weight invalidates the prepared plan)
+    std::vector<void*> derived; int64_t derived_bytes = 0; bool deriving = false;
     int dev_alloc(void** out, size_t bytes) {
         MKD_HIP_CHECK(hipMalloc(out, bytes ? bytes : 16));
-        owned.push_back(*out);
+        if (deriving) { derived.push_back(*out); derived_bytes += (int64_t)bytes; } else owned.push_back(*out);
         weight_bytes += (int64_t)bytes;
         return 0;
     }
@@ -486,7 +490,7 @@ struct mkd_ctx {
         if (rc) return rc;
         if (e != hipSuccess) return mkd_fail(MKD_ERR_HIP, std::string("load_weight sync: ") + hipGetErrorString(e));
         p.loaded = true;
-        if (p.which == 2) vae_finalized = false; else if (p.which == 3) clip_finalized = false; else finalized = false;
+        if (p.which == 2) vae_finalized = false; else if (p.which == 3) clip_finalized = false; else { finalized = false; prepared = false; }
         return 0;
     }
 
@@ -517,6 +521,12 @@ struct mkd_ctx {
             MKD_HIP_CHECK(hipMemset(z, 0, 4096));
             zero_page = (bf16_t*)z;
         }
+        if (!derived.empty()) {
+            MKD_HIP_CHECK(hipDeviceSynchronize());
+            for (void* q : derived) hipFree(q);
+            derived.clear(); weight_bytes -= derived_bytes; derived_bytes = 0;
+        }
+        struct Guard { bool& f; Guard(bool& b) : f(b) { f = true; } ~Guard() { f = false; } } guard(deriving);
         qkv_w.clear(); kv_w.clear(); emb_off.clear(); ffg_w.clear(); ffg_b.clear();
         q2_w.clear(); qkv_s.clear(); qkv_b.clear(); q2_s.clear(); q2_b.clear(); ffg_s.clear(); qkv_plain.clear(); ffp_w.clear(); ffp_b.clear(); ffm_w.clear(); ffm_b.clear();
         tfm_w.clear(); tfm_v.clear(); tfm_hw.clear(); tfm_hv.clear(); fold_w.clear(); fold_b.clear();
@@ -2398,6 +2408,7 @@ struct mkd_ctx {
 
     ~mkd_ctx() {
         for (void* p : owned) hipFree(p);
+        for (void* p : derived) hipFree(p);
         if (gstat_base) hipFree(gstat_base);
         if (varena_base) hipFree(varena_base);
         if (carena_base) hipFree(carena_base);

@@ -582,3 +582,28 @@ def test_plan_options_are_per_context():
         e2.close()
     assert lib.mkd_live_contexts() == n_live
     e1.close()
+
+
+def test_reloading_weights_frees_the_derived_copies_and_invalidates_the_plan():
+    """finalize() derives weight forms (q|k|v and K|V concatenations, LayerNorm folds, merged FF2 . proj_out, packed transformer
+    streams, [W_conv2 | W_skip]): a second load of the weights rebuilds them and frees the previous generation - device memory does not
+    grow - and the prepared plan of the old weights is refused until mkd_prepare ran again."""
+    from makeupdiffuse_amd import lib as mlib
+    e = MkdEngine(NetConfig(**SMALL))
+    e.init_random(3, norm_jitter=0.2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 16, 16, generator=g); hint = torch.rand(2, 6, 128, 128, generator=g); ctx = torch.randn(2, 77, 64, generator=g)
+    t = torch.tensor([801, 201])
+    e.prepare(hint, ctx)
+    a = e.eps(x, t); b0 = e.device_bytes()
+    e.init_random(3, norm_jitter=0.2)                   # every weight again: finalized -> false, plan invalid
+    with pytest.raises(mlib.MkdError):
+        e.eps(x, t)
+    e.prepare(hint, ctx)
+    b = e.eps(x, t)
+    assert torch.equal(a, b)
+    assert e.device_bytes() <= b0 + (1 << 20), (b0, e.device_bytes())
+    e.init_random(4, norm_jitter=0.2)
+    e.prepare(hint, ctx)
+    assert not torch.equal(e.eps(x, t), a) and e.device_bytes() <= b0 + (1 << 20)
+    e.close()
