@@ -68,7 +68,9 @@ void mkd_ctx_destroy(mkd_ctx* ctx);
 
 /* Replaces model.load_state_dict (runs/test.py:59-60) for keys under
  * "model.diffusion_model." and "control_model." (upstream names).
- * `data` is fp32, host OR device, `shape` is host. Synchronous. Unknown names -> MKD_ERR_ARG. */
+ * `data` is fp32, host OR device, `shape` is host. Synchronous. Unknown names -> MKD_ERR_ARG.
+ * Loading a net weight invalidates the prepared conditioning: mkd_eps / mkd_sample fail (MKD_ERR_STATE) until mkd_finalize +
+ * mkd_prepare ran again; the weight forms mkd_finalize derives are rebuilt and their previous generation is freed. */
 int mkd_load_weight(mkd_ctx* ctx, const char* name, const float* data, int ndim, const int64_t* shape);
 /* Checks every expected tensor was loaded, builds fused/packed weights. Synchronous. */
 int mkd_weights_finalize(mkd_ctx* ctx);
@@ -146,7 +148,8 @@ int mkd_sample(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int
  * x_prev += sigma_t * noise * temperature).  sigmas: host array like the other tables (ddim_sigmas[index]); noise: DEVICE array
  * [n_steps][B*4*h*w] fp32, row k = the draw of the k-th executed step (the caller draws them in loop order, as the reference's
  * noise_like does step by step); both NULL, or every sigma 0: mkd_sample.  The graph replays unchanged (the step reads its
- * sigma / noise row from the device-resident step state). */
+ * sigma / noise row from the device-resident step state).  `noise` is read by the enqueued loop: it must stay valid until the work
+ * on `stream` has completed. */
 int mkd_sample_eta(mkd_ctx* ctx, const float* x_T, int batch, int n_steps, const int64_t* timesteps,
                    const float* alphas, const float* alphas_prev, const float* sqrt_one_minus_alphas,
                    const float* sigmas, const float* noise, float temperature,
