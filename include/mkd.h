@@ -69,8 +69,8 @@ void mkd_ctx_destroy(mkd_ctx* ctx);
 /* Replaces model.load_state_dict (runs/test.py:59-60) for keys under
  * "model.diffusion_model." and "control_model." (upstream names).
  * `data` is fp32, host OR device, `shape` is host. Synchronous. Unknown names -> MKD_ERR_ARG.
- * Loading a net weight invalidates the prepared conditioning: mkd_eps / mkd_sample fail (MKD_ERR_STATE) until mkd_finalize +
- * mkd_prepare ran again; the weight forms mkd_finalize derives are rebuilt and their previous generation is freed. */
+ * Loading a net weight invalidates the prepared conditioning: mkd_eps / mkd_sample fail (MKD_ERR_STATE) until mkd_weights_finalize +
+ * mkd_prepare ran again; the weight forms mkd_weights_finalize derives are rebuilt and their previous generation is freed. */
 int mkd_load_weight(mkd_ctx* ctx, const char* name, const float* data, int ndim, const int64_t* shape);
 /* Checks every expected tensor was loaded, builds fused/packed weights. Synchronous. */
 int mkd_weights_finalize(mkd_ctx* ctx);
