@@ -23,9 +23,23 @@ namespace {
 
 using namespace mkdk;
 
+// Taps per K-step (and barrier).  One tap per step: barrier, then every wave's 16 ds_read_b128 queue up at the LDS before its 32 MFMAs -
+// the kernel takes 78 % of its time with NO global loads at all (profiles/exp_r4_conv_ablate.txt).  THREE taps per step (a W stage
+// holds three taps, two stages): a third of the barriers, and the reads of tap t + 1 overlap the MFMAs of tap t inside a step.  Taken
+// where two patch slots + two three-tap W stages fit the 160 KB of LDS (every tile but the 256 x 128 ones).
+#ifndef MKD_CONV_TPS
+#define MKD_CONV_TPS 3
+#endif
+constexpr int conv_tps(int TN, int NW, int PP) {
+    // only where the one-tap form already holds a CU alone (> 80 KB of LDS: its co-residency does not change) and with eight waves or more
+    // (four-wave tiles get slower: six weight pieces per wave and step)
+    return (MKD_CONV_TPS == 3 && NW >= 8 && 2 * PP * NW * 1024 + 3 * TN * 128 > 80 * 1024 && 2 * PP * NW * 1024 + 2 * 3 * TN * 128 + 4096 <= 160 * 1024) ? 3 : 1;
+}
+constexpr int conv_stages(int TN, int NW, int PP, int STAGES) { return conv_tps(TN, NW, PP) == 3 ? 2 : STAGES; }
+
 // GNS = 1: the epilogue also accumulates the GroupNorm statistics of the output (gemm_device.h); separate instantiation so that
 // the plain kernel keeps its registers and occupancy
-template <int TM, int TN, int WM, int WN, int STAGES, int PP, int GNS = 0>
+template <int TM, int TN, int WM, int WN, int STAGES_, int PP, int GNS = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmArgs2 pg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int grp = (int)blockIdx.z >= pg.g[0].gz ? 1 : 0;      // grouped launch: the second problem owns the upper half of grid z
@@ -35,7 +49,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
     constexpr int NI = TN / WN / 16;
     constexpr int MI = TM / WM / 16;
     constexpr int PSLOT = PP * NW * 1024;    // bytes of one patch slot (PP pieces per wave)
-    constexpr int WSB = TN * 128;
+    constexpr int TPS = conv_tps(TN, NW, PP);             // taps per step
+    constexpr int STAGES = conv_stages(TN, NW, PP, STAGES_);
+    constexpr int NTG = 9 / TPS;                           // steps per channel chunk
+    constexpr int WTB = TN * 128;                          // bytes of one tap's W tile
+    constexpr int WSB = TPS * WTB;                         // bytes of one W stage
     static_assert(WP >= 1 && NI >= 1 && MI >= 1 && (NW == 4 || NW == 8 || NW == 16) && STAGES >= 2 && STAGES <= 4, "layout");
 
     const bf16_t* const gA = p.A; const bf16_t* const gW = p.W; const bf16_t* const gZ = p.zero;
@@ -100,12 +118,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
         for (int i = 0; i < PP; ++i)
             glds16(select_src(gA + poff[i] + c * BK, gZ, pok[i]), dst + (w + NW * i) * 1024);
     };
-    auto issue_w = [&](int slot, int c, int tap) {
-        char* dst = wring + slot * WSB;
-        const int k = tap * Cin + c * BK;
+    auto issue_w = [&](int slot, int c, int tg) {          // the TPS taps of step (c, tg)
 #pragma unroll
-        for (int i = 0; i < WP; ++i)
-            glds16(select_src(gW + woff[i] + k, gZ, wok[i]), dst + (w + NW * i) * 1024);
+        for (int t = 0; t < TPS; ++t) {
+            char* dst = wring + slot * WSB + t * WTB;
+            const int k = (tg * TPS + t) * Cin + c * BK;
+#pragma unroll
+            for (int i = 0; i < WP; ++i)
+                glds16(select_src(gW + woff[i] + k, gZ, wok[i]), dst + (w + NW * i) * 1024);
+        }
     };
 
     // ---- MFMA fragment geometry -----------------------------------------------------------------------------
@@ -130,9 +151,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int wslot, int pslot, int tap) {
+    auto compute = [&](int wslot, int pslot, int tg) {
         const char* ps = patch0 + pslot * PSLOT;
-        const char* wsm = wring + wslot * WSB;
+#pragma unroll
+      for (int t = 0; t < TPS; ++t) {
+        const int tap = tg * TPS + t;
+        const char* wsm = wring + wslot * WSB + t * WTB;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dpix = ky * PW + kx;
 #pragma unroll
@@ -155,6 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
+      }
     };
 
     // GNS: (image, group) accumulator of this tile behind the W ring (GACCB bytes, see the launcher), zeroed here
@@ -174,7 +199,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
 
     // ---- K loop over (chunk, tap) ------------------------------------------------------------------------------
     const int nch = c_end - c_begin;
-    const int nsteps = nch * 9;
+    const int nsteps = nch * NTG;
     // bias / residual fragments first: older than every tile load (in-order vmcnt: the counted waits are unaffected), so their
     // latency hides under the K loop instead of being paid after it
     const bool pre = splitk == 1;
@@ -201,12 +226,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
 #pragma unroll
             for (int s = 0; s < STAGES - 1; ++s) {
                 if (s < nsteps) issue_w(s, c_begin + c, tap);
-                if (++tap == 9) { tap = 0; ++c; }
+                if (++tap == NTG) { tap = 0; ++c; }
             }
         }
-        int c = 0, tap = 0;                 // step i = (c, tap)
+        int c = 0, tap = 0;                 // step i = (c, tap group)
         int pc = 0, ptap = STAGES - 1;      // step i + STAGES - 1
-        while (ptap >= 9) { ptap -= 9; ++pc; }
+        while (ptap >= NTG) { ptap -= NTG; ++pc; }
         int wslot = 0, nslot = STAGES - 1;
         int last_patch = -1000;
         for (int i = 0; i < nsteps; ++i) {
@@ -215,18 +240,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const GemmA
             switch (after_w * 2 + (after_p ? 1 : 0)) {
                 case 0: wait_vmcnt<0>(); break;
                 case 1: wait_vmcnt<PP>(); break;
-                case 2: wait_vmcnt<WP>(); break;
-                case 3: wait_vmcnt<WP + PP>(); break;
-                case 4: wait_vmcnt<2 * WP>(); break;
-                default: wait_vmcnt<2 * WP + PP>(); break;
+                case 2: wait_vmcnt<TPS * WP>(); break;
+                case 3: wait_vmcnt<TPS * WP + PP>(); break;
+                case 4: wait_vmcnt<2 * TPS * WP>(); break;
+                default: wait_vmcnt<2 * TPS * WP + PP>(); break;
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (i + STAGES - 1 < nsteps) issue_w(nslot, c_begin + pc, ptap);
             if (tap == 0 && c + 1 < nch) { issue_patch((c + 1) & 1, c_begin + c + 1); last_patch = i; }
             compute(wslot, c & 1, tap);
-            if (++tap == 9) { tap = 0; ++c; }
-            if (++ptap == 9) { ptap = 0; ++pc; }
+            if (++tap == NTG) { tap = 0; ++c; }
+            if (++ptap == NTG) { ptap = 0; ++pc; }
             wslot = (wslot + 1 == STAGES) ? 0 : wslot + 1;
             nslot = (nslot + 1 == STAGES) ? 0 : nslot + 1;
         }
@@ -328,7 +353,7 @@ int launch_patch(const GemmArgs& a, dim3 grid, hipStream_t stream, const GemmArg
     constexpr int STAGES = 3;
     constexpr int NW = WM * WN;
     const bool gns = a.gn_stat != nullptr && a.splitk == 1;
-    const size_t lds = (size_t)2 * PP * NW * 1024 + (size_t)STAGES * TN * 128 + (gns ? 4096 : 0);      // (+ GroupNorm statistics accumulator)
+    const size_t lds = (size_t)2 * PP * NW * 1024 + (size_t)conv_stages(TN, NW, PP, STAGES) * conv_tps(TN, NW, PP) * TN * 128 + (gns ? 4096 : 0);      // (+ GroupNorm statistics accumulator)
     if (lds > 160 * 1024) return mkd_fail(-4, "conv3x3_patch: LDS budget exceeded");
     static bool attr_set[2] = {false, false};
     if (!attr_set[gns]) {
@@ -408,7 +433,7 @@ bool conv_patch_supported(const GemmArgs& a, int cfg) {
     if (!patch_cfg_shape(cfg, &tm, &tn, &nw)) return false;
     int th, tw, im, pp;
     if (!conv_patch_geometry(tm, a.M / (a.Hin * a.Win), a.Hin, a.Win, &th, &tw, &im, &pp, nw)) return false;
-    const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)3 * tn * 128 + (a.gn_stat ? 4096 : 0);
+    const size_t lds = (size_t)2 * pp * nw * 1024 + (size_t)conv_stages(tn, nw, pp, 3) * conv_tps(tn, nw, pp) * tn * 128 + (a.gn_stat ? 4096 : 0);
     return lds <= 160 * 1024;
 }
 

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from makeupdiffuse_amd import lib as mlib
 lib = mlib.load(); P = lambda t: C.c_void_p(None if t is None else t.data_ptr())
 DEV = 'cuda:0'
-SHAPES = [(8, 32, 32, 320, 320, 7), (8, 32, 32, 320, 320, 6), (8, 16, 16, 640, 640, 6), (8, 64, 64, 320, 320, 6), (8, 64, 64, 320, 320, 42)]      # B, H, W, Cin, Cout, tile config
+SHAPES = [(8, 32, 32, 320, 320, 7), (8, 32, 32, 320, 320, 9), (8, 32, 32, 320, 320, 38), (8, 16, 16, 640, 640, 8), (8, 16, 16, 640, 640, 38), (8, 64, 64, 320, 320, 6), (8, 64, 64, 320, 320, 7), (8, 64, 64, 320, 320, 40), (8, 64, 64, 320, 320, 42), (4, 32, 32, 320, 320, 9), (8, 8, 8, 1280, 1280, 9)]      # B, H, W, Cin, Cout, tile config
 for (B, H, W, Cin, Cout, cfg) in SHAPES:
     M = B * H * W
     pool = max(2, (300 << 20) // (Cout * 9 * Cin * 2))
